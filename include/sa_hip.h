@@ -1,0 +1,128 @@
+/*
+ * sa_hip.h -- C ABI of libsa_hip: Needleman-Wunsch score + traceback for many
+ * sequence pairs on one AMD MI355X (gfx950).
+ *
+ * The library stands where the reference's worker pool stands: the reference
+ * fills an array of AlignTask {seq1, seq2, len1, len2, scoring, result}
+ * (include/thread.h:35-42, src/main.c:43-52), wakes its pthread workers
+ * (src/main.c:54-60, include/thread.h:68-85) and, after they finish
+ * (src/main.c:62), formats the Alignment results in pair order
+ * (src/main.c:65-73).  Here the caller uploads the sequences once, submits a
+ * range of rows of a pair schedule, and receives compact result records in
+ * the same pair order; sa_expand_record() turns one record back into what the
+ * reference's Alignment struct holds (include/common.h:19-29).
+ *
+ * Conventions: every function returns 0 on success and a negative code on
+ * failure (sa_strerror() gives the text); the library owns all device and
+ * pinned memory; the caller owns the sequences and whatever it does with the
+ * records.  One context drives one GPU; a context may be used by one
+ * submitting thread and one consuming thread.
+ */
+#ifndef SA_HIP_H
+#define SA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sa_ctx sa_ctx;
+
+/* Pair schedules.
+ * ADJACENT:   pair k = (row k, row k+1), the reference's only schedule
+ *             (src/main.c:43-52, include/user.h:31).  "Row r" of the schedule is pair r.
+ * TRIANGULAR: all pairs (i, j), i < j, row-major, sequence 1 = row i, sequence 2 = row j.
+ *             "Row r" of the schedule is the set of pairs with i = r. */
+#define SA_SCHEDULE_ADJACENT 0
+#define SA_SCHEDULE_TRIANGULAR 1
+
+#define SA_ALPHABET "ARNDCQEGHILKMFPSTWYV"   /* include/scoring.h:6 */
+#define SA_MAX_PEPTIDE_LEN 64
+
+enum {
+    SA_OK = 0,
+    SA_ERR_ARG = -1,          /* bad argument */
+    SA_ERR_ALPHABET = -2,     /* residue outside SA_ALPHABET (undefined behaviour in the reference, include/scoring.h:42) */
+    SA_ERR_LENGTH = -3,       /* empty sequence or longer than the context's max_seq_len */
+    SA_ERR_NOMEM = -4,
+    SA_ERR_STATE = -5,        /* call out of order (nothing uploaded, nothing submitted, ...) */
+    SA_ERR_BUSY = -6,         /* both in-flight slots are in use: call sa_next/sa_release first */
+    SA_ERR_RECORD = -7,       /* record does not describe an alignment of the given sequences */
+    SA_ERR_HIP = -1000        /* -1000 - hipError_t */
+};
+
+/* What the reference's Alignment carries besides the two strings
+ * (include/common.h:19-29); similarity is kept as the integer the reference
+ * prints: (int)(((double)matches / columns) * 10000) (include/seqalign.h:109,
+ * include/csv.h:125). */
+typedef struct {
+    int32_t score;
+    int32_t columns;
+    int32_t matches;
+    int32_t mismatches;
+    int32_t gaps;
+    int32_t similarity_bp;
+} sa_alignment_stats;
+
+/* ---- life cycle: stands for init_thread_pool / destroy_thread_pool
+ * (include/thread.h:87-114) and init_scoring_matrix (include/scoring.h:15-52).
+ * S is the 20x20 substitution matrix indexed [sequence-1 residue][sequence-2
+ * residue] in SA_ALPHABET order (include/seqalign.h:55); NULL selects the
+ * reference's BLOSUM50.  gap is the linear gap penalty (include/user.h:13). */
+int sa_init(sa_ctx** ctx, const int32_t* S, int32_t gap, uint32_t max_seq_len, int device);
+void sa_destroy(sa_ctx* ctx);
+const char* sa_strerror(int code);
+
+/* ---- sequences: stands for the seqs[] / seq_lens[] batch arrays the reference
+ * parses into (src/main.c:25-37).  codes are residue indices 0..19 (what
+ * AMINO_LOOKUP yields, include/seqalign.h:41-44), sequence s occupying
+ * codes[offs[s] .. offs[s]+lens[s]).  Rows keep their file order. */
+int sa_encode(const char* seq, uint32_t len, uint8_t* codes);
+int sa_upload(sa_ctx* ctx, const uint8_t* codes, const uint64_t* offs, const uint32_t* lens, uint64_t nseq);
+
+/* ---- schedule arithmetic (no device work) */
+uint64_t sa_schedule_rows(const sa_ctx* ctx, int schedule);                 /* number of rows */
+uint64_t sa_pair_index(const sa_ctx* ctx, int schedule, uint64_t row);      /* canonical index of the row's first pair */
+uint64_t sa_pair_count(const sa_ctx* ctx, int schedule, uint64_t row_begin, uint64_t row_end);
+uint64_t sa_cell_count(const sa_ctx* ctx, int schedule, uint64_t row_begin, uint64_t row_end); /* sum len1*len2 */
+uint32_t sa_record_stride(const sa_ctx* ctx);                               /* bytes per result record */
+/* split [0, rows) into `parts` contiguous row ranges of near-equal cell count;
+ * bounds receives parts+1 row indices */
+int sa_shard_rows(const sa_ctx* ctx, int schedule, uint32_t parts, uint64_t* bounds);
+
+/* ---- dispatch: stands for filling g_thread_work[] + sem_post(work_ready)
+ * (src/main.c:54-60) and sem_wait(work_done) (src/main.c:62).
+ * sa_submit starts the kernels for rows [row_begin,row_end) and the copy of
+ * their records to pinned host memory, and returns at once.  sa_next blocks
+ * until the oldest submission is complete and hands out its records, which
+ * stay valid until sa_release.  Two submissions may be in flight. */
+int sa_submit(sa_ctx* ctx, int schedule, uint64_t row_begin, uint64_t row_end);
+int sa_next(sa_ctx* ctx, const uint8_t** records, uint64_t* first_pair, uint64_t* npairs);
+int sa_release(sa_ctx* ctx);
+
+/* ---- measurement: the same kernels with the records left in device memory.
+ * sa_prepare_resident builds the work list and buffers for the row range once;
+ * sa_run_resident launches the kernels over it (kernel_ms: HIP-event time on the
+ * launch stream); sa_fetch_resident copies records [first, first+n) of the
+ * range (relative to its first pair) to host memory. */
+int sa_prepare_resident(sa_ctx* ctx, int schedule, uint64_t row_begin, uint64_t row_end);
+int sa_run_resident(sa_ctx* ctx, float* kernel_ms);
+int sa_fetch_resident(sa_ctx* ctx, uint64_t first, uint64_t n, uint8_t* dst);
+/* tuning knobs: LDS bytes for traceback rows per wave (multiple of 1024),
+ * tiles per work item, workgroups per CU; 0 keeps the current value */
+int sa_set_tuning(sa_ctx* ctx, uint32_t lds_dir_bytes, uint32_t tiles_per_item, uint32_t wg_per_cu);
+
+/* ---- records -> what the reference's Alignment holds (host only, no GPU).
+ * seq1/seq2 are the ASCII sequences of the pair; a1/a2 receive the aligned
+ * strings (columns+1 bytes each, NUL-terminated). */
+int sa_expand_record(const uint8_t* record, uint32_t stride, const char* seq1, uint32_t len1,
+                     const char* seq2, uint32_t len2, char* a1, char* a2, sa_alignment_stats* st);
+int sa_similarity_bp(int32_t matches, int32_t columns);
+void sa_default_matrix(int32_t S[400]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,227 @@
+"""ctypes binding of libsa_hip.so (C ABI: include/sa_hip.h).
+
+Mirrors the seam of the reference program: sequences are parsed once
+(src/main.c:25-37), a batch of pairs is dispatched (src/main.c:54-62) and the
+results come back in pair order (src/main.c:65-73).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+ADJACENT = 0
+TRIANGULAR = 1
+ALPHABET = "ARNDCQEGHILKMFPSTWYV"
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def lib_path():
+    return os.path.join(_HERE, "libsa_hip.so")
+
+
+class SaError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__(f"libsa_hip error {code}: {text}")
+        self.code = code
+
+
+class AlignmentStats(C.Structure):
+    _fields_ = [
+        ("score", C.c_int32),
+        ("columns", C.c_int32),
+        ("matches", C.c_int32),
+        ("mismatches", C.c_int32),
+        ("gaps", C.c_int32),
+        ("similarity_bp", C.c_int32),
+    ]
+
+
+_lib = None
+
+# every entry point include/sa_hip.h declares: name -> (restype, argtypes)
+_u8p = C.POINTER(C.c_uint8)
+SIGNATURES = {
+    "sa_init": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int32, C.c_uint32, C.c_int]),
+    "sa_destroy": (None, [C.c_void_p]),
+    "sa_strerror": (C.c_char_p, [C.c_int]),
+    "sa_encode": (C.c_int, [C.c_char_p, C.c_uint32, _u8p]),
+    "sa_upload": (C.c_int, [C.c_void_p, _u8p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_uint64]),
+    "sa_schedule_rows": (C.c_uint64, [C.c_void_p, C.c_int]),
+    "sa_pair_index": (C.c_uint64, [C.c_void_p, C.c_int, C.c_uint64]),
+    "sa_pair_count": (C.c_uint64, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64]),
+    "sa_cell_count": (C.c_uint64, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64]),
+    "sa_record_stride": (C.c_uint32, [C.c_void_p]),
+    "sa_shard_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.POINTER(C.c_uint64)]),
+    "sa_submit": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64]),
+    "sa_next": (C.c_int, [C.c_void_p, C.POINTER(_u8p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "sa_release": (C.c_int, [C.c_void_p]),
+    "sa_prepare_resident": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64]),
+    "sa_run_resident": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "sa_fetch_resident": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, _u8p]),
+    "sa_set_tuning": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "sa_expand_record": (
+        C.c_int,
+        [_u8p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_char_p, C.c_char_p,
+         C.POINTER(AlignmentStats)],
+    ),
+    "sa_similarity_bp": (C.c_int, [C.c_int32, C.c_int32]),
+    "sa_default_matrix": (None, [C.POINTER(C.c_int32)]),
+}
+
+
+def load_library():
+    """Load libsa_hip.so and bind every declared symbol (raises if one is missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise SaError(-1, f"{path} is not built (run `make lib`); there is no CPU fallback")
+    lib = C.CDLL(path)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise SaError(rc, load_library().sa_strerror(rc).decode())
+
+
+def similarity_bp(matches, columns):
+    return load_library().sa_similarity_bp(matches, columns)
+
+
+class Aligner:
+    """One GPU context: upload sequences once, align row ranges of a schedule."""
+
+    def __init__(self, gap=-4, matrix=None, max_seq_len=64, device=0):
+        lib = load_library()
+        self._lib = lib
+        self._ctx = C.c_void_p()
+        mat = None
+        if matrix is not None:
+            m = np.ascontiguousarray(matrix, dtype=np.int32).reshape(400)
+            mat = m.ctypes.data_as(C.POINTER(C.c_int32))
+            self._matrix = m
+        _check(lib.sa_init(C.byref(self._ctx), mat, gap, max_seq_len, device))
+        self.seqs = []
+
+    def close(self):
+        if self._ctx:
+            self._lib.sa_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- sequences
+    def upload(self, seqs):
+        seqs = [s.encode() if isinstance(s, str) else bytes(s) for s in seqs]
+        lens = np.array([len(s) for s in seqs], dtype=np.uint32)
+        offs = np.zeros(len(seqs), dtype=np.uint64)
+        if len(seqs) > 1:
+            offs[1:] = np.cumsum(lens[:-1], dtype=np.uint64)
+        blob = b"".join(seqs)
+        codes = np.zeros(max(1, len(blob)), dtype=np.uint8)
+        _check(self._lib.sa_encode(blob, len(blob), codes.ctypes.data_as(_u8p)))
+        _check(
+            self._lib.sa_upload(
+                self._ctx,
+                codes.ctypes.data_as(_u8p),
+                offs.ctypes.data_as(C.POINTER(C.c_uint64)),
+                lens.ctypes.data_as(C.POINTER(C.c_uint32)),
+                len(seqs),
+            )
+        )
+        self.seqs = seqs
+
+    # -- schedule arithmetic
+    def rows(self, schedule):
+        return self._lib.sa_schedule_rows(self._ctx, schedule)
+
+    def pair_index(self, schedule, row):
+        return self._lib.sa_pair_index(self._ctx, schedule, row)
+
+    def pair_count(self, schedule, r0, r1):
+        return self._lib.sa_pair_count(self._ctx, schedule, r0, r1)
+
+    def cell_count(self, schedule, r0, r1):
+        return self._lib.sa_cell_count(self._ctx, schedule, r0, r1)
+
+    @property
+    def stride(self):
+        return self._lib.sa_record_stride(self._ctx)
+
+    def shard_rows(self, schedule, parts):
+        b = (C.c_uint64 * (parts + 1))()
+        _check(self._lib.sa_shard_rows(self._ctx, schedule, parts, b))
+        return list(b)
+
+    def set_tuning(self, lds_dir_bytes=0, tiles_per_item=0, wg_per_cu=0):
+        _check(self._lib.sa_set_tuning(self._ctx, lds_dir_bytes, tiles_per_item, wg_per_cu))
+
+    # -- dispatch
+    def submit(self, schedule, r0, r1):
+        _check(self._lib.sa_submit(self._ctx, schedule, r0, r1))
+
+    def next(self):
+        """Records of the oldest submission as a (npairs, stride) uint8 view, plus its first pair index."""
+        rec = _u8p()
+        first = C.c_uint64()
+        n = C.c_uint64()
+        _check(self._lib.sa_next(self._ctx, C.byref(rec), C.byref(first), C.byref(n)))
+        if n.value == 0:
+            return np.zeros((0, self.stride), dtype=np.uint8), first.value
+        arr = np.ctypeslib.as_array(rec, shape=(n.value * self.stride,)).reshape(n.value, self.stride)
+        return arr, first.value
+
+    def release(self):
+        _check(self._lib.sa_release(self._ctx))
+
+    def align(self, schedule, r0=0, r1=None):
+        """Align rows [r0, r1) and return a copy of their records."""
+        if r1 is None:
+            r1 = self.rows(schedule)
+        self.submit(schedule, r0, r1)
+        rec, _ = self.next()
+        out = rec.copy()
+        self.release()
+        return out
+
+    # -- measurement path (records stay on the device)
+    def prepare_resident(self, schedule, r0, r1):
+        _check(self._lib.sa_prepare_resident(self._ctx, schedule, r0, r1))
+
+    def run_resident(self):
+        ms = C.c_float()
+        _check(self._lib.sa_run_resident(self._ctx, C.byref(ms)))
+        return ms.value
+
+    def fetch_resident(self, first, n):
+        out = np.zeros((n, self.stride), dtype=np.uint8)
+        _check(self._lib.sa_fetch_resident(self._ctx, first, n, out.ctypes.data_as(_u8p)))
+        return out
+
+    # -- records
+    def expand(self, record, i, j):
+        """Aligned strings and statistics of the pair (file rows i, j) from its record."""
+        s1, s2 = self.seqs[i], self.seqs[j]
+        n = len(s1) + len(s2) + 1
+        a1 = C.create_string_buffer(n)
+        a2 = C.create_string_buffer(n)
+        st = AlignmentStats()
+        rec = np.ascontiguousarray(record, dtype=np.uint8)
+        _check(
+            self._lib.sa_expand_record(
+                rec.ctypes.data_as(_u8p), rec.size, s1, len(s1), s2, len(s2), a1, a2, C.byref(st)
+            )
+        )
+        return a1.value, a2.value, st

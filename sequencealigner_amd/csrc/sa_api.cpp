@@ -1,0 +1,597 @@
+// sa_api.cpp -- host side of libsa_hip: context, sequence upload (length
+// bucketing and tiling), work-list construction, launches, result streaming.
+// The C ABI is declared in include/sa_hip.h.  There is no CPU fallback: every
+// compute entry point needs a working HIP device and fails with a HIP error
+// code otherwise.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/sa_hip.h"
+#include "sa_device.h"
+
+extern "C" void sa_launch_peptide(int mode, const SaPepParams* p, unsigned grid, unsigned lds_bytes,
+                                  hipStream_t stream);
+
+namespace {
+
+// BLOSUM50 over SA_ALPHABET (the matrix of include/scoring.h:16-36)
+const int8_t kBlosum50[400] = {
+     5,-2,-1,-2,-1,-1,-1, 0,-2,-1,-2,-1,-1,-3,-1, 1, 0,-3,-2, 0,
+    -2, 7,-1,-2,-4, 1, 0,-3, 0,-4,-3, 3,-2,-3,-3,-1,-1,-3,-1,-3,
+    -1,-1, 7, 2,-2, 0, 0, 0, 1,-3,-4, 0,-2,-4,-2, 1, 0,-4,-2,-3,
+    -2,-2, 2, 8,-4, 0, 2,-1,-1,-4,-4,-1,-4,-5,-1, 0,-1,-5,-3,-4,
+    -1,-4,-2,-4,13,-3,-3,-3,-3,-2,-2,-3,-2,-2,-4,-1,-1,-5,-3,-1,
+    -1, 1, 0, 0,-3, 7, 2,-2, 1,-3,-2, 2, 0,-4,-1, 0,-1,-1,-1,-3,
+    -1, 0, 0, 2,-3, 2, 6,-3, 0,-4,-3, 1,-2,-3,-1,-1,-1,-3,-2,-3,
+     0,-3, 0,-1,-3,-2,-3, 8,-2,-4,-4,-2,-3,-4,-2, 0,-2,-3,-3,-4,
+    -2, 0, 1,-1,-3, 1, 0,-2,10,-4,-3, 0,-1,-1,-2,-1,-2,-3, 2,-4,
+    -1,-4,-3,-4,-2,-3,-4,-4,-4, 5, 2,-3, 2, 0,-3,-3,-1,-3,-1, 4,
+    -2,-3,-4,-4,-2,-2,-3,-4,-3, 2, 5,-3, 3, 1,-4,-3,-1,-2,-1, 1,
+    -1, 3, 0,-1,-3, 2, 1,-2, 0,-3,-3, 6,-2,-4,-1, 0,-1,-3,-2,-3,
+    -1,-2,-2,-4,-2, 0,-2,-3,-1, 2, 3,-2, 7, 0,-3,-2,-1,-1, 0, 1,
+    -3,-3,-4,-5,-2,-4,-3,-4,-1, 0, 1,-4, 0, 8,-4,-3,-2, 1, 4,-1,
+    -1,-3,-2,-1,-4,-1,-1,-2,-2,-3,-4,-1,-3,-4,10,-1,-1,-4,-3,-3,
+     1,-1, 1, 0,-1, 0,-1, 0,-1,-3,-3, 0,-2,-3,-1, 5, 2,-4,-2,-2,
+     0,-1, 0,-1,-1,-1,-1,-2,-2,-1,-1,-1,-1,-2,-1, 2, 5,-3,-2, 0,
+    -3,-3,-4,-5,-5,-1,-3,-3,-3,-3,-2,-3,-1, 1,-4,-4,-3,15, 2,-3,
+    -2,-1,-2,-3,-3,-1,-2,-3, 2,-1,-1,-2, 0, 4,-3,-2,-2, 2, 8,-1,
+     0,-3,-3,-4,-1,-3,-3,-4,-4, 4, 1,-3, 1,-1,-3,-2, 0,-3,-1, 5,
+};
+
+inline int hip_code(hipError_t e) { return e == hipSuccess ? SA_OK : SA_ERR_HIP - (int)e; }
+
+#define SA_HIP_TRY(expr)                          \
+    do {                                          \
+        hipError_t e_ = (expr);                   \
+        if (e_ != hipSuccess) return hip_code(e_); \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return SA_OK;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return hip_code(e); }
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) { p = nullptr; return hip_code(e); }
+        cap = bytes;
+        return SA_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct PinBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return SA_OK;
+        if (p) { hipError_t e = hipHostFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return hip_code(e); }
+        hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+        if (e != hipSuccess) { p = nullptr; return hip_code(e); }
+        cap = bytes;
+        return SA_OK;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+struct Work {                 // one submitted (or prepared) row range
+    DevBuf items, out, counter;
+    PinBuf host;
+    hipEvent_t kernel_done = nullptr, copied = nullptr, t0 = nullptr, t1 = nullptr;
+    uint32_t nitems = 0;
+    int schedule = 0;
+    uint64_t first_pair = 0, npairs = 0;
+    bool busy = false;
+};
+
+}  // namespace
+
+struct sa_ctx {
+    int device = 0;
+    int ncu = 0;
+    int32_t S[400];
+    int32_t gap = -4;
+    uint32_t max_len = 64;
+    hipStream_t compute = nullptr, copy = nullptr;
+    // tuning
+    uint32_t lds_dir_bytes = 15 * 1024;
+    uint32_t tiles_per_item = 8;
+    uint32_t wg_per_cu = 8;
+    // sequences (host mirror)
+    uint64_t nseq = 0;
+    std::vector<uint8_t> len;          // file order
+    std::vector<uint64_t> len_suffix;  // len_suffix[i] = sum of len[i..]
+    uint32_t max_seq = 0;              // longest uploaded sequence
+    uint32_t stride = 80;
+    // buckets
+    struct Bucket { uint32_t tile_begin, ntiles; std::vector<uint32_t> fi; };
+    std::vector<Bucket> buckets;
+    std::vector<uint16_t> bucket_of;   // file index -> bucket
+    uint32_t ntiles = 0;
+    // device
+    DevBuf d_codes, d_len, d_tiles, d_tile_fi, d_tile_len, d_tile_maxlen, d_sprime, d_spill;
+    uint32_t spill_grid = 0;
+    Work slots[2];
+    int head = 0, tail = 0, inflight = 0;
+    Work resident;
+    bool resident_ready = false;
+};
+
+namespace {
+
+uint64_t tri_row_start(uint64_t n, uint64_t i) { return i * (2 * n - i - 1) / 2; }
+
+int build_items(const sa_ctx* c, int schedule, uint64_t r0, uint64_t r1, std::vector<SaItem>& items) {
+    items.clear();
+    if (schedule == SA_SCHEDULE_ADJACENT) {
+        for (uint64_t k = r0; k < r1; k += 64) {
+            SaItem it;
+            it.p = (uint32_t)k; it.tile_begin = 0;
+            it.count = (uint32_t)std::min<uint64_t>(64, r1 - k); it.reserved = 0;
+            items.push_back(it);
+        }
+        return SA_OK;
+    }
+    const size_t nb = c->buckets.size();
+    // cursor[b] = number of sequences of bucket b with file index <= p
+    std::vector<uint32_t> cursor(nb);
+    for (size_t b = 0; b < nb; b++) {
+        const auto& fi = c->buckets[b].fi;
+        cursor[b] = (uint32_t)(std::upper_bound(fi.begin(), fi.end(), (uint32_t)r0) - fi.begin());
+    }
+    const uint32_t per = c->tiles_per_item;
+    for (uint64_t p = r0; p < r1; p++) {
+        if (p > r0) cursor[c->bucket_of[p]]++;
+        for (size_t b = 0; b < nb; b++) {
+            const auto& B = c->buckets[b];
+            const uint32_t pos = cursor[b];
+            if (pos >= B.fi.size()) continue;
+            uint32_t t = B.tile_begin + pos / 64;
+            const uint32_t tend = B.tile_begin + B.ntiles;
+            while (t < tend) {
+                SaItem it;
+                it.p = (uint32_t)p; it.tile_begin = t;
+                it.count = std::min(per, tend - t); it.reserved = 0;
+                items.push_back(it);
+                t += it.count;
+            }
+        }
+    }
+    return SA_OK;
+}
+
+int ensure_spill(sa_ctx* c, uint32_t grid) {
+    if (grid <= c->spill_grid) return SA_OK;
+    int rc = c->d_spill.reserve((size_t)grid * SA_LP * 1024);
+    if (rc) return rc;
+    c->spill_grid = grid;
+    return SA_OK;
+}
+
+uint32_t grid_for(const sa_ctx* c) {
+    const uint32_t lds = SA_LDS_FIXED_BYTES + c->lds_dir_bytes;
+    uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>(c->wg_per_cu, (160u * 1024u) / lds));
+    return (uint32_t)c->ncu * per_cu;
+}
+
+// queue the kernels of one row range on the compute stream
+int launch_work(sa_ctx* c, Work& w, bool timed) {
+    if (w.npairs == 0 || w.nitems == 0) return SA_OK;
+    const uint32_t grid = grid_for(c);
+    int rc = ensure_spill(c, grid);
+    if (rc) return rc;
+    SA_HIP_TRY(hipMemsetAsync(w.counter.p, 0, 256, c->compute));
+    SaPepParams P;
+    memset(&P, 0, sizeof(P));
+    P.codes_fo = (const uint8_t*)c->d_codes.p;
+    P.len_fo = (const uint8_t*)c->d_len.p;
+    P.tiles = (const uint8_t*)c->d_tiles.p;
+    P.tile_fi = (const uint32_t*)c->d_tile_fi.p;
+    P.tile_len = (const uint8_t*)c->d_tile_len.p;
+    P.tile_maxlen = (const uint8_t*)c->d_tile_maxlen.p;
+    P.sprime = (const int32_t*)c->d_sprime.p;
+    P.items = (const SaItem*)w.items.p;
+    P.nitems = w.nitems;
+    P.counter = (uint32_t*)w.counter.p;
+    P.out = (uint8_t*)w.out.p;
+    P.stride = c->stride;
+    P.out_base_pair = w.first_pair;
+    P.spill = (uint32_t*)c->d_spill.p;
+    P.spill_rows = SA_LP;
+    P.nseq = (uint32_t)c->nseq;
+    P.gap = c->gap;
+    P.lds_dir_bytes = c->lds_dir_bytes;
+    if (timed) SA_HIP_TRY(hipEventRecord(w.t0, c->compute));
+    sa_launch_peptide(w.schedule == SA_SCHEDULE_TRIANGULAR ? 0 : 1, &P, grid,
+                      SA_LDS_FIXED_BYTES + c->lds_dir_bytes, c->compute);
+    SA_HIP_TRY(hipGetLastError());
+    if (timed) SA_HIP_TRY(hipEventRecord(w.t1, c->compute));
+    return SA_OK;
+}
+
+int prepare_work(sa_ctx* c, Work& w, int schedule, uint64_t r0, uint64_t r1, bool need_host) {
+    std::vector<SaItem> items;
+    int rc = build_items(c, schedule, r0, r1, items);
+    if (rc) return rc;
+    w.schedule = schedule;
+    w.first_pair = sa_pair_index(c, schedule, r0);
+    w.npairs = sa_pair_count(c, schedule, r0, r1);
+    w.nitems = (uint32_t)items.size();
+    if ((rc = w.counter.reserve(256))) return rc;
+    if ((rc = w.items.reserve(std::max<size_t>(16, items.size() * sizeof(SaItem))))) return rc;
+    if ((rc = w.out.reserve(std::max<size_t>(16, w.npairs * (size_t)c->stride)))) return rc;
+    if (need_host && (rc = w.host.reserve(std::max<size_t>(16, w.npairs * (size_t)c->stride)))) return rc;
+    if (!items.empty())
+        SA_HIP_TRY(hipMemcpyAsync(w.items.p, items.data(), items.size() * sizeof(SaItem),
+                                  hipMemcpyHostToDevice, c->compute));
+    // the item vector is pageable memory: the copy must have consumed it before it goes away
+    SA_HIP_TRY(hipStreamSynchronize(c->compute));
+    return SA_OK;
+}
+
+int init_events(Work& w) {
+    SA_HIP_TRY(hipEventCreate(&w.kernel_done));
+    SA_HIP_TRY(hipEventCreate(&w.copied));
+    SA_HIP_TRY(hipEventCreate(&w.t0));
+    SA_HIP_TRY(hipEventCreate(&w.t1));
+    return SA_OK;
+}
+
+void free_work(Work& w) {
+    w.items.release(); w.out.release(); w.counter.release(); w.host.release();
+    if (w.kernel_done) (void)hipEventDestroy(w.kernel_done);
+    if (w.copied) (void)hipEventDestroy(w.copied);
+    if (w.t0) (void)hipEventDestroy(w.t0);
+    if (w.t1) (void)hipEventDestroy(w.t1);
+}
+
+}  // namespace
+
+extern "C" {
+
+void sa_default_matrix(int32_t S[400]) {
+    for (int k = 0; k < 400; k++) S[k] = kBlosum50[k];
+}
+
+const char* sa_strerror(int code) {
+    switch (code) {
+        case SA_OK: return "ok";
+        case SA_ERR_ARG: return "bad argument";
+        case SA_ERR_ALPHABET: return "residue outside the 20-letter alphabet";
+        case SA_ERR_LENGTH: return "empty sequence or sequence longer than the context allows";
+        case SA_ERR_NOMEM: return "out of host memory";
+        case SA_ERR_STATE: return "call out of order";
+        case SA_ERR_BUSY: return "two submissions already in flight";
+        case SA_ERR_RECORD: return "record does not match the sequences";
+        default: break;
+    }
+    if (code <= SA_ERR_HIP) return hipGetErrorString((hipError_t)(SA_ERR_HIP - code));
+    return "unknown error";
+}
+
+int sa_encode(const char* seq, uint32_t len, uint8_t* codes) {
+    static const char alphabet[] = SA_ALPHABET;
+    int8_t lut[128];
+    memset(lut, -1, sizeof(lut));
+    for (int k = 0; k < 20; k++) lut[(int)alphabet[k]] = (int8_t)k;
+    for (uint32_t i = 0; i < len; i++) {
+        const unsigned char ch = (unsigned char)seq[i];
+        if (ch > 127 || lut[ch] < 0) return SA_ERR_ALPHABET;
+        codes[i] = (uint8_t)lut[ch];
+    }
+    return SA_OK;
+}
+
+int sa_similarity_bp(int32_t matches, int32_t columns) {
+    if (columns <= 0) return 0;
+    // quotient first, then the scaling, both in IEEE double, then truncation
+    volatile double q = (double)matches / (double)columns;
+    volatile double scaled = q * 10000.0;
+    return (int)scaled;
+}
+
+int sa_init(sa_ctx** out, const int32_t* S, int32_t gap, uint32_t max_seq_len, int device) {
+    if (!out || max_seq_len == 0) return SA_ERR_ARG;
+    if (max_seq_len > SA_MAX_PEPTIDE_LEN) return SA_ERR_LENGTH;
+    int ndev = 0;
+    SA_HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return SA_ERR_ARG;
+    SA_HIP_TRY(hipSetDevice(device));
+    sa_ctx* c = new (std::nothrow) sa_ctx();
+    if (!c) return SA_ERR_NOMEM;
+    c->device = device;
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) { delete c; return hip_code(e); }
+    c->ncu = prop.multiProcessorCount;
+    if (S) memcpy(c->S, S, sizeof(c->S)); else sa_default_matrix(c->S);
+    c->gap = gap;
+    c->max_len = max_seq_len;
+    int rc = SA_OK;
+    do {
+        if ((e = hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking)) != hipSuccess) { rc = hip_code(e); break; }
+        if ((e = hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking)) != hipSuccess) { rc = hip_code(e); break; }
+        if ((rc = init_events(c->slots[0]))) break;
+        if ((rc = init_events(c->slots[1]))) break;
+        if ((rc = init_events(c->resident))) break;
+        // S' = S - 2*gap, padded: row 20 (padding residue) and columns >= 20 score 0
+        std::vector<int32_t> sp(21 * SA_SPRIME_STRIDE, 0);
+        for (int a = 0; a < 20; a++)
+            for (int b = 0; b < 20; b++) sp[a * SA_SPRIME_STRIDE + b] = c->S[a * 20 + b] - 2 * gap;
+        if ((rc = c->d_sprime.reserve(sp.size() * 4))) break;
+        if ((e = hipMemcpy(c->d_sprime.p, sp.data(), sp.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) { rc = hip_code(e); break; }
+    } while (0);
+    if (rc) { sa_destroy(c); return rc; }
+    *out = c;
+    return SA_OK;
+}
+
+void sa_destroy(sa_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->compute) (void)hipStreamSynchronize(c->compute);
+    if (c->copy) (void)hipStreamSynchronize(c->copy);
+    free_work(c->slots[0]); free_work(c->slots[1]); free_work(c->resident);
+    c->d_codes.release(); c->d_len.release(); c->d_tiles.release(); c->d_tile_fi.release();
+    c->d_tile_len.release(); c->d_tile_maxlen.release(); c->d_sprime.release(); c->d_spill.release();
+    if (c->compute) (void)hipStreamDestroy(c->compute);
+    if (c->copy) (void)hipStreamDestroy(c->copy);
+    delete c;
+}
+
+int sa_set_tuning(sa_ctx* c, uint32_t lds_dir_bytes, uint32_t tiles_per_item, uint32_t wg_per_cu) {
+    if (!c) return SA_ERR_ARG;
+    if (lds_dir_bytes) {
+        if (lds_dir_bytes % 1024 || SA_LDS_FIXED_BYTES + lds_dir_bytes > 64 * 1024) return SA_ERR_ARG;
+        c->lds_dir_bytes = lds_dir_bytes;
+    }
+    if (tiles_per_item) c->tiles_per_item = tiles_per_item;
+    if (wg_per_cu) c->wg_per_cu = wg_per_cu;
+    c->resident_ready = false;
+    return SA_OK;
+}
+
+int sa_upload(sa_ctx* c, const uint8_t* codes, const uint64_t* offs, const uint32_t* lens, uint64_t nseq) {
+    if (!c || !codes || !offs || !lens) return SA_ERR_ARG;
+    if (nseq == 0 || nseq >= 0xFFFFFFF0ull) return SA_ERR_ARG;
+    if (c->inflight) return SA_ERR_STATE;
+    SA_HIP_TRY(hipSetDevice(c->device));
+    uint32_t lmin = 0xFFFFFFFFu, lmax = 0;
+    for (uint64_t s = 0; s < nseq; s++) {
+        if (lens[s] == 0 || lens[s] > c->max_len) return SA_ERR_LENGTH;
+        lmin = std::min(lmin, lens[s]); lmax = std::max(lmax, lens[s]);
+        for (uint32_t i = 0; i < lens[s]; i++)
+            if (codes[offs[s] + i] >= 20) return SA_ERR_ALPHABET;
+    }
+    c->nseq = nseq;
+    c->max_seq = lmax;
+    c->stride = (SA_REC_HEADER_BYTES + lmax + 15u) & ~15u;
+    c->resident_ready = false;
+
+    // file-order slots, right-aligned; two spare slots so that rows read past a slot stay inside the buffer
+    std::vector<uint8_t> slots((size_t)(nseq + 2) * SA_LP, SA_PAD_CODE);
+    c->len.assign(nseq, 0);
+    for (uint64_t s = 0; s < nseq; s++) {
+        c->len[s] = (uint8_t)lens[s];
+        memcpy(&slots[(size_t)s * SA_LP + (SA_LP - lens[s])], codes + offs[s], lens[s]);
+    }
+    c->len_suffix.assign(nseq + 1, 0);
+    for (uint64_t s = nseq; s-- > 0;) c->len_suffix[s] = c->len_suffix[s + 1] + c->len[s];
+
+    // length buckets: exact lengths when every length has plenty of sequences, wider otherwise
+    const uint32_t range = lmax - lmin + 1;
+    uint32_t width = (uint32_t)((256ull * range + nseq - 1) / nseq);
+    width = std::max(1u, std::min(width, 64u));
+    const uint32_t nb = (range + width - 1) / width;
+    c->buckets.assign(nb, sa_ctx::Bucket());
+    c->bucket_of.assign(nseq, 0);
+    for (uint64_t s = 0; s < nseq; s++) {
+        const uint32_t b = (lens[s] - lmin) / width;
+        c->bucket_of[s] = (uint16_t)b;
+        c->buckets[b].fi.push_back((uint32_t)s);   // ascending file index by construction
+    }
+    uint32_t t = 0;
+    for (auto& B : c->buckets) {
+        B.tile_begin = t;
+        B.ntiles = (uint32_t)((B.fi.size() + 63) / 64);
+        t += B.ntiles;
+    }
+    c->ntiles = t;
+    std::vector<uint8_t> tiles((size_t)t * 4096 + 4096, SA_PAD_CODE);
+    std::vector<uint32_t> tile_fi((size_t)t * 64 + 64, SA_INVALID_FI);
+    std::vector<uint8_t> tile_len((size_t)t * 64 + 64, 0);
+    std::vector<uint8_t> tile_maxlen((size_t)t + 64, 0);
+    for (const auto& B : c->buckets) {
+        for (size_t k = 0; k < B.fi.size(); k++) {
+            const uint32_t s = B.fi[k];
+            const uint32_t tile = B.tile_begin + (uint32_t)(k / 64), lane = (uint32_t)(k % 64);
+            tile_fi[(size_t)tile * 64 + lane] = s;
+            tile_len[(size_t)tile * 64 + lane] = (uint8_t)lens[s];
+            tile_maxlen[tile] = std::max<uint8_t>(tile_maxlen[tile], (uint8_t)lens[s]);
+            for (uint32_t i = 0; i < lens[s]; i++)
+                tiles[(size_t)tile * 4096 + (size_t)i * 64 + lane] = codes[offs[s] + i];
+        }
+    }
+    int rc;
+    if ((rc = c->d_codes.reserve(slots.size()))) return rc;
+    if ((rc = c->d_len.reserve(nseq + 64))) return rc;
+    if ((rc = c->d_tiles.reserve(tiles.size()))) return rc;
+    if ((rc = c->d_tile_fi.reserve(tile_fi.size() * 4))) return rc;
+    if ((rc = c->d_tile_len.reserve(tile_len.size()))) return rc;
+    if ((rc = c->d_tile_maxlen.reserve(tile_maxlen.size()))) return rc;
+    SA_HIP_TRY(hipMemcpy(c->d_codes.p, slots.data(), slots.size(), hipMemcpyHostToDevice));
+    SA_HIP_TRY(hipMemset(c->d_len.p, 0, nseq + 64));
+    SA_HIP_TRY(hipMemcpy(c->d_len.p, c->len.data(), nseq, hipMemcpyHostToDevice));
+    SA_HIP_TRY(hipMemcpy(c->d_tiles.p, tiles.data(), tiles.size(), hipMemcpyHostToDevice));
+    SA_HIP_TRY(hipMemcpy(c->d_tile_fi.p, tile_fi.data(), tile_fi.size() * 4, hipMemcpyHostToDevice));
+    SA_HIP_TRY(hipMemcpy(c->d_tile_len.p, tile_len.data(), tile_len.size(), hipMemcpyHostToDevice));
+    SA_HIP_TRY(hipMemcpy(c->d_tile_maxlen.p, tile_maxlen.data(), tile_maxlen.size(), hipMemcpyHostToDevice));
+    return SA_OK;
+}
+
+uint64_t sa_schedule_rows(const sa_ctx* c, int schedule) {
+    if (!c || c->nseq < 2) return 0;
+    (void)schedule;
+    return c->nseq - 1;   // ADJACENT: pairs 0..n-2; TRIANGULAR: first rows 0..n-2
+}
+
+uint64_t sa_pair_index(const sa_ctx* c, int schedule, uint64_t row) {
+    if (!c) return 0;
+    if (schedule == SA_SCHEDULE_ADJACENT) return row;
+    return tri_row_start(c->nseq, row);
+}
+
+uint64_t sa_pair_count(const sa_ctx* c, int schedule, uint64_t r0, uint64_t r1) {
+    if (!c || r1 <= r0) return 0;
+    return sa_pair_index(c, schedule, r1) - sa_pair_index(c, schedule, r0);
+}
+
+uint64_t sa_cell_count(const sa_ctx* c, int schedule, uint64_t r0, uint64_t r1) {
+    if (!c || r1 <= r0) return 0;
+    uint64_t cells = 0;
+    for (uint64_t i = r0; i < r1; i++) {
+        if (schedule == SA_SCHEDULE_ADJACENT) cells += (uint64_t)c->len[i] * c->len[i + 1];
+        else cells += (uint64_t)c->len[i] * c->len_suffix[i + 1];
+    }
+    return cells;
+}
+
+uint32_t sa_record_stride(const sa_ctx* c) { return c ? c->stride : 0; }
+
+int sa_shard_rows(const sa_ctx* c, int schedule, uint32_t parts, uint64_t* bounds) {
+    if (!c || !bounds || parts == 0) return SA_ERR_ARG;
+    const uint64_t rows = sa_schedule_rows(c, schedule);
+    const uint64_t total = sa_cell_count(c, schedule, 0, rows);
+    uint64_t acc = 0, row = 0;
+    bounds[0] = 0;
+    for (uint32_t k = 1; k < parts; k++) {
+        const uint64_t target = total / parts * k;
+        while (row < rows && acc < target) {
+            acc += schedule == SA_SCHEDULE_ADJACENT ? (uint64_t)c->len[row] * c->len[row + 1]
+                                                    : (uint64_t)c->len[row] * c->len_suffix[row + 1];
+            row++;
+        }
+        bounds[k] = row;
+    }
+    bounds[parts] = rows;
+    return SA_OK;
+}
+
+int sa_submit(sa_ctx* c, int schedule, uint64_t r0, uint64_t r1) {
+    if (!c || (schedule != SA_SCHEDULE_ADJACENT && schedule != SA_SCHEDULE_TRIANGULAR)) return SA_ERR_ARG;
+    if (c->nseq < 2) return SA_ERR_STATE;
+    if (r1 < r0 || r1 > sa_schedule_rows(c, schedule)) return SA_ERR_ARG;
+    if (c->inflight == 2) return SA_ERR_BUSY;
+    SA_HIP_TRY(hipSetDevice(c->device));
+    Work& w = c->slots[c->head];
+    int rc = prepare_work(c, w, schedule, r0, r1, true);
+    if (rc) return rc;
+    if ((rc = launch_work(c, w, false))) return rc;
+    SA_HIP_TRY(hipEventRecord(w.kernel_done, c->compute));
+    SA_HIP_TRY(hipStreamWaitEvent(c->copy, w.kernel_done, 0));
+    if (w.npairs)
+        SA_HIP_TRY(hipMemcpyAsync(w.host.p, w.out.p, w.npairs * (size_t)c->stride, hipMemcpyDeviceToHost, c->copy));
+    SA_HIP_TRY(hipEventRecord(w.copied, c->copy));
+    w.busy = true;
+    c->head ^= 1;
+    c->inflight++;
+    return SA_OK;
+}
+
+int sa_next(sa_ctx* c, const uint8_t** records, uint64_t* first_pair, uint64_t* npairs) {
+    if (!c || !records || !first_pair || !npairs) return SA_ERR_ARG;
+    if (c->inflight == 0) return SA_ERR_STATE;
+    Work& w = c->slots[c->tail];
+    SA_HIP_TRY(hipEventSynchronize(w.copied));
+    *records = (const uint8_t*)w.host.p;
+    *first_pair = w.first_pair;
+    *npairs = w.npairs;
+    return SA_OK;
+}
+
+int sa_release(sa_ctx* c) {
+    if (!c) return SA_ERR_ARG;
+    if (c->inflight == 0) return SA_ERR_STATE;
+    c->slots[c->tail].busy = false;
+    c->tail ^= 1;
+    c->inflight--;
+    return SA_OK;
+}
+
+int sa_prepare_resident(sa_ctx* c, int schedule, uint64_t r0, uint64_t r1) {
+    if (!c || (schedule != SA_SCHEDULE_ADJACENT && schedule != SA_SCHEDULE_TRIANGULAR)) return SA_ERR_ARG;
+    if (c->nseq < 2) return SA_ERR_STATE;
+    if (r1 < r0 || r1 > sa_schedule_rows(c, schedule)) return SA_ERR_ARG;
+    SA_HIP_TRY(hipSetDevice(c->device));
+    c->resident_ready = false;
+    int rc = prepare_work(c, c->resident, schedule, r0, r1, false);
+    if (rc) return rc;
+    c->resident_ready = true;
+    return SA_OK;
+}
+
+int sa_run_resident(sa_ctx* c, float* kernel_ms) {
+    if (!c) return SA_ERR_ARG;
+    if (!c->resident_ready) return SA_ERR_STATE;
+    SA_HIP_TRY(hipSetDevice(c->device));
+    int rc = launch_work(c, c->resident, true);
+    if (rc) return rc;
+    SA_HIP_TRY(hipStreamSynchronize(c->compute));
+    if (kernel_ms) {
+        *kernel_ms = 0.f;
+        if (c->resident.npairs && c->resident.nitems)
+            SA_HIP_TRY(hipEventElapsedTime(kernel_ms, c->resident.t0, c->resident.t1));
+    }
+    return SA_OK;
+}
+
+int sa_fetch_resident(sa_ctx* c, uint64_t first, uint64_t n, uint8_t* dst) {
+    if (!c || !dst) return SA_ERR_ARG;
+    if (!c->resident_ready) return SA_ERR_STATE;
+    if (first + n > c->resident.npairs) return SA_ERR_ARG;
+    SA_HIP_TRY(hipSetDevice(c->device));
+    if (n)
+        SA_HIP_TRY(hipMemcpy(dst, (const uint8_t*)c->resident.out.p + first * c->stride, n * (size_t)c->stride,
+                             hipMemcpyDeviceToHost));
+    return SA_OK;
+}
+
+int sa_expand_record(const uint8_t* rec, uint32_t stride, const char* seq1, uint32_t len1, const char* seq2,
+                     uint32_t len2, char* a1, char* a2, sa_alignment_stats* st) {
+    if (!rec || !seq1 || !seq2 || !a1 || !a2 || !st) return SA_ERR_ARG;
+    if (stride < SA_REC_HEADER_BYTES || len2 > stride - SA_REC_HEADER_BYTES) return SA_ERR_RECORD;
+    int32_t score; uint16_t matches, gaps;
+    memcpy(&score, rec, 4); memcpy(&matches, rec + 4, 2); memcpy(&gaps, rec + 6, 2);
+    const uint8_t* body = rec + SA_REC_HEADER_BYTES;
+    const uint32_t columns = len1 + gaps;     // every column holds a residue of sequence 1 or one of its gaps
+    uint32_t pos = columns, j = len1, ups = 0;
+    for (uint32_t k = 0; k < len2; k++) {
+        const uint32_t i = len2 - k, run = body[k] >> 1, up = body[k] & 1;
+        if (run > j || pos < run + 1) return SA_ERR_RECORD;
+        for (uint32_t x = 0; x < run; x++) { --pos; a1[pos] = seq1[--j]; a2[pos] = '-'; }
+        --pos;
+        if (up) { a1[pos] = '-'; a2[pos] = seq2[i - 1]; ups++; }
+        else {
+            if (j == 0) return SA_ERR_RECORD;
+            a1[pos] = seq1[--j]; a2[pos] = seq2[i - 1];
+        }
+    }
+    if (pos != j || ups != gaps) return SA_ERR_RECORD;
+    while (j > 0) { --pos; a1[pos] = seq1[--j]; a2[pos] = '-'; }
+    a1[columns] = a2[columns] = '\0';
+    st->score = score;
+    st->columns = (int32_t)columns;
+    st->matches = matches;
+    st->gaps = gaps;
+    st->mismatches = (int32_t)columns - matches - gaps;
+    st->similarity_bp = sa_similarity_bp(matches, (int32_t)columns);
+    return SA_OK;
+}
+
+}  // extern "C"

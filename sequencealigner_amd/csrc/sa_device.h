@@ -1,0 +1,77 @@
+/*
+ * sa_device.h -- data layout shared by the host side of the library and the
+ * HIP kernels (plain C structs, no HIP types).
+ *
+ * Sequences live on the device twice:
+ *   file order, one 64-byte slot per sequence, residue codes RIGHT-aligned
+ *     (slot[64-len .. 64) = codes, the rest = SA_PAD_CODE).  A slot is the
+ *     column operand of the DP: register column c holds slot[c], so the last
+ *     residue is always in column 63 and the final score in a fixed register.
+ *   length-bucketed tiles, 64 sequences per tile, stored position-major
+ *     (tile[pos][lane], LEFT-aligned, 4 KiB per tile): lane l of a wave reads
+ *     row residue i of "its" sequence with one coalesced 64-byte load.
+ *     Within a bucket the sequences are ordered by file index, so for a given
+ *     first sequence p the partners with a larger file index form a suffix of
+ *     each bucket.
+ */
+#ifndef SA_DEVICE_H
+#define SA_DEVICE_H
+
+#include <stdint.h>
+
+#define SA_LP 64                 /* DP columns held in registers by the peptide kernel */
+#define SA_PAD_CODE 20           /* residue code of padding; its substitution scores are 0 */
+#define SA_INVALID_FI 0xFFFFFFFFu
+#define SA_SPRIME_STRIDE 32      /* dwords per row of the shifted substitution table */
+
+/* LDS carve-up of the peptide kernel (bytes) */
+#define SA_LDS_PROF_BYTES 5376   /* 21 rows x 64 dwords (query profile) */
+#define SA_LDS_EMASK_BYTES 192   /* 21 x 8 B equality masks, padded */
+#define SA_LDS_STAGE_DWORDS 20   /* per-lane staging record: 80 B */
+#define SA_LDS_STAGE_BYTES (64 * SA_LDS_STAGE_DWORDS * 4)
+#define SA_LDS_FIXED_BYTES (SA_LDS_PROF_BYTES + SA_LDS_EMASK_BYTES + SA_LDS_STAGE_BYTES)
+
+/* One unit of work pulled from the device-side queue.
+ * TRIANGULAR: first sequence p (file index) against tiles [tile_begin, tile_begin+count).
+ * ADJACENT:   pairs (p+l, p+l+1) for l in [0, count), count <= 64. */
+typedef struct {
+    uint32_t p;
+    uint32_t tile_begin;
+    uint32_t count;
+    uint32_t reserved;
+} SaItem;
+
+/* Result record, `stride` bytes per pair (multiple of 16):
+ *   int32  score
+ *   uint16 matches
+ *   uint16 gaps          (columns where sequence 1 has '-')
+ *   uint8  body[stride-8]
+ * body[k], k = 0..len2-1, describes row i = len2-k of the traceback:
+ *   bits 7..1 = number of LEFT moves taken in that row before leaving it,
+ *   bit 0     = how the row was left: 0 = DIAG, 1 = UP.
+ * Whatever is left of sequence 1 after row 1 is consumed by LEFT moves. */
+#define SA_REC_HEADER_BYTES 8
+
+typedef struct {
+    const uint8_t* codes_fo;     /* [N][64] right-aligned residue codes, file order */
+    const uint8_t* len_fo;       /* [N] */
+    const uint8_t* tiles;        /* [T][64 pos][64 lanes] left-aligned codes */
+    const uint32_t* tile_fi;     /* [T*64] file index of each tile slot or SA_INVALID_FI */
+    const uint8_t* tile_len;     /* [T*64] */
+    const uint8_t* tile_maxlen;  /* [T] */
+    const int32_t* sprime;       /* [21][32] S[a][b] - 2*gap; row 20 and columns >= 20 are 0 */
+    const SaItem* items;
+    uint32_t nitems;
+    uint32_t* counter;           /* work-queue head, zeroed before the launch */
+    uint8_t* out;                /* records, canonical pair order */
+    uint32_t stride;             /* bytes per record */
+    uint64_t out_base_pair;      /* canonical pair index of out[0] */
+    uint32_t* spill;             /* direction rows that do not fit in LDS: per workgroup
+                                    spill_rows x 64 lanes x 4 dwords */
+    uint32_t spill_rows;
+    uint32_t nseq;
+    int32_t gap;
+    uint32_t lds_dir_bytes;      /* LDS bytes for direction rows (multiple of 1024) */
+} SaPepParams;
+
+#endif
