@@ -114,6 +114,12 @@ int sa_fetch_resident(sa_ctx* ctx, uint64_t first, uint64_t n, uint8_t* dst);
  * tiles per work item, workgroups per CU; 0 keeps the current value */
 int sa_set_tuning(sa_ctx* ctx, uint32_t lds_dir_bytes, uint32_t tiles_per_item, uint32_t wg_per_cu);
 
+/* diagnostic: with enable != 0 the next launches accumulate shader cycles per kernel
+ * phase (0 queue fetch, 1 profile build, 2 operand set-up, 3 fill, 4 traceback,
+ * 5 record store), summed over workgroups; totals (may be NULL) receives the sums of
+ * the previous launch.  Timed launches run a few percent slower. */
+int sa_debug_phase_cycles(sa_ctx* ctx, int enable, uint64_t totals[8]);
+
 /* ---- records -> what the reference's Alignment holds (host only, no GPU).
  * seq1/seq2 are the ASCII sequences of the pair; a1/a2 receive the aligned
  * strings (columns+1 bytes each, NUL-terminated). */

@@ -65,6 +65,7 @@ SIGNATURES = {
         [_u8p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_char_p, C.c_char_p,
          C.POINTER(AlignmentStats)],
     ),
+    "sa_debug_phase_cycles": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]),
     "sa_similarity_bp": (C.c_int, [C.c_int32, C.c_int32]),
     "sa_default_matrix": (None, [C.POINTER(C.c_int32)]),
 }
@@ -209,6 +210,12 @@ class Aligner:
         out = np.zeros((n, self.stride), dtype=np.uint8)
         _check(self._lib.sa_fetch_resident(self._ctx, first, n, out.ctypes.data_as(_u8p)))
         return out
+
+    def phase_cycles(self, enable=True):
+        """Shader-cycle totals per kernel phase of the previous timed launch; (re)arms the timers."""
+        tot = (C.c_uint64 * 8)()
+        _check(self._lib.sa_debug_phase_cycles(self._ctx, 1 if enable else 0, tot))
+        return list(tot)
 
     # -- records
     def expand(self, record, i, j):

@@ -115,7 +115,8 @@ struct sa_ctx {
     std::vector<uint16_t> bucket_of;   // file index -> bucket
     uint32_t ntiles = 0;
     // device
-    DevBuf d_codes, d_len, d_tiles, d_tile_fi, d_tile_len, d_tile_maxlen, d_sprime, d_spill;
+    DevBuf d_codes, d_len, d_tiles, d_tile_fi, d_tile_len, d_tile_maxlen, d_sprime, d_spill, d_phase;
+    bool phase_timers = false;
     uint32_t spill_grid = 0;
     Work slots[2];
     int head = 0, tail = 0, inflight = 0;
@@ -207,6 +208,11 @@ int launch_work(sa_ctx* c, Work& w, bool timed) {
     P.nseq = (uint32_t)c->nseq;
     P.gap = c->gap;
     P.lds_dir_bytes = c->lds_dir_bytes;
+    if (c->phase_timers) {
+        if ((rc = c->d_phase.reserve((size_t)grid * 64))) return rc;
+        SA_HIP_TRY(hipMemsetAsync(c->d_phase.p, 0, (size_t)grid * 64, c->compute));
+        P.phase_cycles = (unsigned long long*)c->d_phase.p;
+    }
     if (timed) SA_HIP_TRY(hipEventRecord(w.t0, c->compute));
     sa_launch_peptide(w.schedule == SA_SCHEDULE_TRIANGULAR ? 0 : 1, &P, grid,
                       SA_LDS_FIXED_BYTES + c->lds_dir_bytes, c->compute);
@@ -340,6 +346,7 @@ void sa_destroy(sa_ctx* c) {
     free_work(c->slots[0]); free_work(c->slots[1]); free_work(c->resident);
     c->d_codes.release(); c->d_len.release(); c->d_tiles.release(); c->d_tile_fi.release();
     c->d_tile_len.release(); c->d_tile_maxlen.release(); c->d_sprime.release(); c->d_spill.release();
+    c->d_phase.release();
     if (c->compute) (void)hipStreamDestroy(c->compute);
     if (c->copy) (void)hipStreamDestroy(c->copy);
     delete c;
@@ -374,12 +381,12 @@ int sa_upload(sa_ctx* c, const uint8_t* codes, const uint64_t* offs, const uint3
     c->stride = (SA_REC_HEADER_BYTES + lmax + 15u) & ~15u;
     c->resident_ready = false;
 
-    // file-order slots, right-aligned; two spare slots so that rows read past a slot stay inside the buffer
+    // file-order slots, left-aligned, padded with SA_PAD_CODE (plus two spare slots)
     std::vector<uint8_t> slots((size_t)(nseq + 2) * SA_LP, SA_PAD_CODE);
     c->len.assign(nseq, 0);
     for (uint64_t s = 0; s < nseq; s++) {
         c->len[s] = (uint8_t)lens[s];
-        memcpy(&slots[(size_t)s * SA_LP + (SA_LP - lens[s])], codes + offs[s], lens[s]);
+        memcpy(&slots[(size_t)s * SA_LP], codes + offs[s], lens[s]);
     }
     c->len_suffix.assign(nseq + 1, 0);
     for (uint64_t s = nseq; s-- > 0;) c->len_suffix[s] = c->len_suffix[s + 1] + c->len[s];
@@ -562,6 +569,23 @@ int sa_fetch_resident(sa_ctx* c, uint64_t first, uint64_t n, uint8_t* dst) {
     return SA_OK;
 }
 
+int sa_debug_phase_cycles(sa_ctx* c, int enable, uint64_t totals[8]) {
+    if (!c) return SA_ERR_ARG;
+    SA_HIP_TRY(hipSetDevice(c->device));
+    if (totals) {
+        for (int k = 0; k < 8; k++) totals[k] = 0;
+        if (c->phase_timers && c->d_phase.p) {
+            const uint32_t grid = grid_for(c);
+            std::vector<uint64_t> h((size_t)grid * 8);
+            SA_HIP_TRY(hipMemcpy(h.data(), c->d_phase.p, h.size() * 8, hipMemcpyDeviceToHost));
+            for (uint32_t g = 0; g < grid; g++)
+                for (int k = 0; k < 8; k++) totals[k] += h[(size_t)g * 8 + k];
+        }
+    }
+    c->phase_timers = enable != 0;
+    return SA_OK;
+}
+
 int sa_expand_record(const uint8_t* rec, uint32_t stride, const char* seq1, uint32_t len1, const char* seq2,
                      uint32_t len2, char* a1, char* a2, sa_alignment_stats* st) {
     if (!rec || !seq1 || !seq2 || !a1 || !a2 || !st) return SA_ERR_ARG;
@@ -572,7 +596,7 @@ int sa_expand_record(const uint8_t* rec, uint32_t stride, const char* seq1, uint
     const uint32_t columns = len1 + gaps;     // every column holds a residue of sequence 1 or one of its gaps
     uint32_t pos = columns, j = len1, ups = 0;
     for (uint32_t k = 0; k < len2; k++) {
-        const uint32_t i = len2 - k, run = body[k] >> 1, up = body[k] & 1;
+        const uint32_t i = len2 - k, run = body[i - 1] >> 1, up = body[i - 1] & 1;
         if (run > j || pos < run + 1) return SA_ERR_RECORD;
         for (uint32_t x = 0; x < run; x++) { --pos; a1[pos] = seq1[--j]; a2[pos] = '-'; }
         --pos;

@@ -3,10 +3,9 @@
  * HIP kernels (plain C structs, no HIP types).
  *
  * Sequences live on the device twice:
- *   file order, one 64-byte slot per sequence, residue codes RIGHT-aligned
- *     (slot[64-len .. 64) = codes, the rest = SA_PAD_CODE).  A slot is the
- *     column operand of the DP: register column c holds slot[c], so the last
- *     residue is always in column 63 and the final score in a fixed register.
+ *   file order, one 64-byte slot per sequence (slot[0 .. len) = residue codes,
+ *     the rest = SA_PAD_CODE).  A slot is the column operand of the DP:
+ *     register column c holds slot[c].
  *   length-bucketed tiles, 64 sequences per tile, stored position-major
  *     (tile[pos][lane], LEFT-aligned, 4 KiB per tile): lane l of a wave reads
  *     row residue i of "its" sequence with one coalesced 64-byte load.
@@ -25,7 +24,11 @@
 #define SA_SPRIME_STRIDE 32      /* dwords per row of the shifted substitution table */
 
 /* LDS carve-up of the peptide kernel (bytes) */
-#define SA_LDS_PROF_BYTES 5376   /* 21 rows x 64 dwords (query profile) */
+/* Query-profile rows are 68 dwords apart: a row is read 16 bytes per lane with the
+ * lanes of a wave in different rows (one per row residue), and a stride of 64 dwords
+ * would put every row on the same four LDS banks. */
+#define SA_PROF_STRIDE 68
+#define SA_LDS_PROF_BYTES (21 * SA_PROF_STRIDE * 4)   /* 21 rows (20 residues + padding) */
 #define SA_LDS_EMASK_BYTES 192   /* 21 x 8 B equality masks, padded */
 #define SA_LDS_STAGE_DWORDS 20   /* per-lane staging record: 80 B */
 #define SA_LDS_STAGE_BYTES (64 * SA_LDS_STAGE_DWORDS * 4)
@@ -46,14 +49,15 @@ typedef struct {
  *   uint16 matches
  *   uint16 gaps          (columns where sequence 1 has '-')
  *   uint8  body[stride-8]
- * body[k], k = 0..len2-1, describes row i = len2-k of the traceback:
+ * body[r], r = 0..len2-1, describes how the traceback crosses DP row i = r+1
+ * (the traceback itself runs from row len2 down to row 1):
  *   bits 7..1 = number of LEFT moves taken in that row before leaving it,
  *   bit 0     = how the row was left: 0 = DIAG, 1 = UP.
  * Whatever is left of sequence 1 after row 1 is consumed by LEFT moves. */
 #define SA_REC_HEADER_BYTES 8
 
 typedef struct {
-    const uint8_t* codes_fo;     /* [N][64] right-aligned residue codes, file order */
+    const uint8_t* codes_fo;     /* [N][64] residue codes padded with SA_PAD_CODE, file order */
     const uint8_t* len_fo;       /* [N] */
     const uint8_t* tiles;        /* [T][64 pos][64 lanes] left-aligned codes */
     const uint32_t* tile_fi;     /* [T*64] file index of each tile slot or SA_INVALID_FI */
@@ -72,6 +76,7 @@ typedef struct {
     uint32_t nseq;
     int32_t gap;
     uint32_t lds_dir_bytes;      /* LDS bytes for direction rows (multiple of 1024) */
+    unsigned long long* phase_cycles;  /* optional [grid][8] shader-cycle totals per phase, or NULL */
 } SaPepParams;
 
 #endif

@@ -13,14 +13,14 @@
 // are identical to the reference; per cell it costs one add and one max3
 // instead of three adds and two max.
 //
-// The DP row lives in VGPRs (64 columns, the sequence of the columns is
-// right-aligned so the last column is register 63; padding columns score 0 and
-// stay 0).  Two register banks alternate between rows so no copies are needed.
+// The DP row lives in VGPRs (up to 64 columns, processed four at a time; a row
+// stops after the last group that holds a residue of sequence 1).  Two register
+// banks alternate between rows so no copies are needed.
 // Per cell two direction bits are produced from sign bits, (m-h)<0 and (up-h)<0,
 // and shifted into per-row bit planes with v_alignbit.  Rows of direction bits
 // go to LDS while they fit and to a per-workgroup global spill area after that.
 // The traceback walks one row per step: the run of LEFT moves inside a row is
-// a count-trailing-ones on (plane_nd & plane_nu).
+// a count-trailing-ones on (plane_nd & plane_nu); its output is one byte per row.
 //
 // TRIANGULAR mode: all lanes of a wave share sequence 1 (file row p); its
 // substitution scores are expanded once into an LDS "query profile"
@@ -55,55 +55,207 @@ __device__ __forceinline__ int wave_min(int v) {
     return v;
 }
 
-// One DP row: IN = previous row, OUT = this row, columns 4*g0 .. 63.
-// sc  = in: substitution scores of the first active group for this row
-//       out: those of the next row (prefetched while the last group runs)
-template <int MODE>
-__device__ __forceinline__ void fill_row(const int (&IN)[SA_LP], int (&OUT)[SA_LP], const int g0,
-                                         const int32_t* __restrict__ row_base,
-                                         const int32_t* __restrict__ next_row_base,
-                                         const int (&a4)[SA_LP], int4& sc,
-                                         uint32_t& alo, uint32_t& ahi, uint32_t& blo, uint32_t& bhi) {
+// One DP cell.  up/diag come from the previous row's bank, left from this row's.
+// The two direction bits are the sign bits of (m - h) and (up - h).
+#define SA_CELL(IN, OUT, C, S, PA, PB)                                     \
+    {                                                                      \
+        const int diag_ = ((C) == 0) ? 0 : IN[((C) == 0) ? 0 : (C) - 1];   \
+        const int left_ = ((C) == 0) ? 0 : OUT[((C) == 0) ? 0 : (C) - 1];  \
+        const int up_ = IN[C];                                             \
+        const int m_ = diag_ + (S);                                        \
+        const int h_ = max3i(m_, up_, left_);                              \
+        PA = shift_in_sign(PA, m_ - h_);                                   \
+        PB = shift_in_sign(PB, up_ - h_);                                  \
+        OUT[C] = h_;                                                       \
+    }
+
+// Four columns of a TRIANGULAR row.  CUR holds their substitution scores; the
+// scores of the next four columns are requested first so that the LDS latency
+// is covered by the 24 arithmetic instructions of this group (a row of the
+// profile is 68 dwords apart from the next, so the request after the last group
+// stays inside the row's padding).  Rows end early: gend = ceil(len1 / 4).
+#define SA_GROUP_TRI(G, CUR, NXT, PA, PB)                                          \
+    NXT = *reinterpret_cast<const int4*>(row_base + 4 * ((G) + 1));                \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+    SA_CELL(IN, OUT, 4 * (G) + 0, CUR.x, PA, PB)                                   \
+    SA_CELL(IN, OUT, 4 * (G) + 1, CUR.y, PA, PB)                                   \
+    SA_CELL(IN, OUT, 4 * (G) + 2, CUR.z, PA, PB)                                   \
+    SA_CELL(IN, OUT, 4 * (G) + 3, CUR.w, PA, PB)                                   \
+    if (gend == (G) + 1) return;
+
+// One DP row of the TRIANGULAR kernel: IN = previous row, OUT = this row,
+// columns 0 .. 4*gend-1 (gend is wave-uniform).  sc0: in = scores of columns
+// 0..3 for this row, out = the same for the next row (requested at the top of
+// the row, used one row later).
+__device__ __forceinline__ void fill_row_tri(const int (&IN)[SA_LP], int (&OUT)[SA_LP], const int gend,
+                                             const int32_t* __restrict__ row_base,
+                                             const int32_t* __restrict__ next_row_base, int4& sc0,
+                                             uint32_t& alo, uint32_t& ahi, uint32_t& blo, uint32_t& bhi) {
+    int4 scE = sc0, scO;
+    sc0 = *reinterpret_cast<const int4*>(next_row_base);
+    SA_GROUP_TRI(0, scE, scO, alo, blo)
+    SA_GROUP_TRI(1, scO, scE, alo, blo)
+    SA_GROUP_TRI(2, scE, scO, alo, blo)
+    SA_GROUP_TRI(3, scO, scE, alo, blo)
+    SA_GROUP_TRI(4, scE, scO, alo, blo)
+    SA_GROUP_TRI(5, scO, scE, alo, blo)
+    SA_GROUP_TRI(6, scE, scO, alo, blo)
+    SA_GROUP_TRI(7, scO, scE, alo, blo)
+    SA_GROUP_TRI(8, scE, scO, ahi, bhi)
+    SA_GROUP_TRI(9, scO, scE, ahi, bhi)
+    SA_GROUP_TRI(10, scE, scO, ahi, bhi)
+    SA_GROUP_TRI(11, scO, scE, ahi, bhi)
+    SA_GROUP_TRI(12, scE, scO, ahi, bhi)
+    SA_GROUP_TRI(13, scO, scE, ahi, bhi)
+    SA_GROUP_TRI(14, scE, scO, ahi, bhi)
+    SA_GROUP_TRI(15, scO, scE, ahi, bhi)
+}
+
+// One DP row of the ADJACENT kernel (every lane has its own column sequence):
+// scores come from an LDS copy of S', row selected by the row residue, entry by
+// the column residue (a4 = 4 * residue code).
+__device__ __forceinline__ void fill_row_adj(const int (&IN)[SA_LP], int (&OUT)[SA_LP], const int gend,
+                                             const int32_t* __restrict__ row_base, const int (&a4)[SA_LP],
+                                             uint32_t& alo, uint32_t& ahi, uint32_t& blo, uint32_t& bhi) {
+    const char* rb = reinterpret_cast<const char*>(row_base);
 #pragma unroll
     for (int g = 0; g < SA_LP / 4; g++) {
-        if (g >= g0) {   // wave-uniform
-            int4 nx;
-            if (MODE == SA_MODE_TRI) {
-                // next group of this row, or the first active group of the next row
-                const int32_t* src = (g == SA_LP / 4 - 1) ? next_row_base + 4 * g0 : row_base + 4 * (g + 1);
-                nx = *reinterpret_cast<const int4*>(src);
+        if (g < gend) {   // wave-uniform
+            const int s0 = *reinterpret_cast<const int32_t*>(rb + a4[4 * g + 0]);
+            const int s1 = *reinterpret_cast<const int32_t*>(rb + a4[4 * g + 1]);
+            const int s2 = *reinterpret_cast<const int32_t*>(rb + a4[4 * g + 2]);
+            const int s3 = *reinterpret_cast<const int32_t*>(rb + a4[4 * g + 3]);
+            if (g < 8) {
+                SA_CELL(IN, OUT, 4 * g + 0, s0, alo, blo)
+                SA_CELL(IN, OUT, 4 * g + 1, s1, alo, blo)
+                SA_CELL(IN, OUT, 4 * g + 2, s2, alo, blo)
+                SA_CELL(IN, OUT, 4 * g + 3, s3, alo, blo)
             } else {
-                if (g == SA_LP / 4 - 1) {
-                    nx.x = nx.y = nx.z = nx.w = 0;   // reloaded by the caller for the next row
-                } else {
-                    const char* rb = reinterpret_cast<const char*>(row_base);
-                    nx.x = *reinterpret_cast<const int32_t*>(rb + a4[4 * g + 4]);
-                    nx.y = *reinterpret_cast<const int32_t*>(rb + a4[4 * g + 5]);
-                    nx.z = *reinterpret_cast<const int32_t*>(rb + a4[4 * g + 6]);
-                    nx.w = *reinterpret_cast<const int32_t*>(rb + a4[4 * g + 7]);
-                }
+                SA_CELL(IN, OUT, 4 * g + 0, s0, ahi, bhi)
+                SA_CELL(IN, OUT, 4 * g + 1, s1, ahi, bhi)
+                SA_CELL(IN, OUT, 4 * g + 2, s2, ahi, bhi)
+                SA_CELL(IN, OUT, 4 * g + 3, s3, ahi, bhi)
             }
-            const int s[4] = {sc.x, sc.y, sc.z, sc.w};
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int c = 4 * g + k;
-                const int diag = (c == 0) ? 0 : IN[c - 1];
-                const int left = (c == 0) ? 0 : OUT[c - 1];
-                const int up = IN[c];
-                const int m = diag + s[k];
-                const int h = max3i(m, up, left);
-                if (c < 32) {
-                    alo = shift_in_sign(alo, m - h);
-                    blo = shift_in_sign(blo, up - h);
-                } else {
-                    ahi = shift_in_sign(ahi, m - h);
-                    bhi = shift_in_sign(bhi, up - h);
-                }
-                OUT[c] = h;
-            }
-            sc = nx;
         }
     }
+}
+
+// value of register column `col` (wave-uniform) of a row bank
+#define SA_PICK_CASE(C) case C: v = BANK[C]; break;
+__device__ __forceinline__ int pick_column(const int (&BANK)[SA_LP], const int col) {
+    int v = 0;
+    switch (col) {
+        SA_PICK_CASE(0) SA_PICK_CASE(1) SA_PICK_CASE(2) SA_PICK_CASE(3) SA_PICK_CASE(4) SA_PICK_CASE(5) SA_PICK_CASE(6) SA_PICK_CASE(7)
+        SA_PICK_CASE(8) SA_PICK_CASE(9) SA_PICK_CASE(10) SA_PICK_CASE(11) SA_PICK_CASE(12) SA_PICK_CASE(13) SA_PICK_CASE(14) SA_PICK_CASE(15)
+        SA_PICK_CASE(16) SA_PICK_CASE(17) SA_PICK_CASE(18) SA_PICK_CASE(19) SA_PICK_CASE(20) SA_PICK_CASE(21) SA_PICK_CASE(22) SA_PICK_CASE(23)
+        SA_PICK_CASE(24) SA_PICK_CASE(25) SA_PICK_CASE(26) SA_PICK_CASE(27) SA_PICK_CASE(28) SA_PICK_CASE(29) SA_PICK_CASE(30) SA_PICK_CASE(31)
+        SA_PICK_CASE(32) SA_PICK_CASE(33) SA_PICK_CASE(34) SA_PICK_CASE(35) SA_PICK_CASE(36) SA_PICK_CASE(37) SA_PICK_CASE(38) SA_PICK_CASE(39)
+        SA_PICK_CASE(40) SA_PICK_CASE(41) SA_PICK_CASE(42) SA_PICK_CASE(43) SA_PICK_CASE(44) SA_PICK_CASE(45) SA_PICK_CASE(46) SA_PICK_CASE(47)
+        SA_PICK_CASE(48) SA_PICK_CASE(49) SA_PICK_CASE(50) SA_PICK_CASE(51) SA_PICK_CASE(52) SA_PICK_CASE(53) SA_PICK_CASE(54) SA_PICK_CASE(55)
+        SA_PICK_CASE(56) SA_PICK_CASE(57) SA_PICK_CASE(58) SA_PICK_CASE(59) SA_PICK_CASE(60) SA_PICK_CASE(61) SA_PICK_CASE(62) SA_PICK_CASE(63)
+        default: break;
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------- traceback
+// Bottom row first, four rows per step of the outer loop so that the loads of a
+// whole chunk (direction words from LDS or from the spill area, row residues)
+// are in flight together and one chunk ahead of their use.  A row shifted
+// ncols = 4*gend direction bits into each plane, so column c sits at bit
+// (ncols-1-c): plane A says "cell != diag + S'", plane B "cell != up".  PT is
+// uint32_t when ncols <= 32 (one word per plane) and uint64_t otherwise.
+struct SaChunk {
+    uint4 d[4];
+    int b[4];
+};
+
+template <int MODE, typename PT>
+__device__ __forceinline__ void traceback(const int lane, const int maxlen, const int lenq, const int lenp,
+                                          const int ncols, const int rows_lds, const uint32_t* __restrict__ dirs,
+                                          const uint32_t* __restrict__ spill, const uint8_t* __restrict__ brow,
+                                          const int bstep, const uint8_t* __restrict__ acol,
+                                          const uint64_t* __restrict__ emask, uint32_t* __restrict__ stage_rec,
+                                          int& matches_out, int& gaps_out) {
+    constexpr bool WIDE = sizeof(PT) == 8;
+    int j = lenp, matches = 0, gaps = 0;
+    const int nhi = ncols - 32;                              // WIDE: columns held by the second word
+    const uint32_t himask = WIDE ? (uint32_t)((1ull << nhi) - 1) : 0;
+
+    auto load_chunk = [&](int ch, SaChunk& ck) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int r = 4 * ch + k;
+            ck.d[k] = make_uint4(0, 0, 0, 0);
+            ck.b[k] = SA_PAD_CODE;
+            if (r < maxlen) {   // wave-uniform
+                if (r < rows_lds) {
+                    if (WIDE) ck.d[k] = *reinterpret_cast<const uint4*>(dirs + (r * 64 + lane) * 4);
+                    else { const uint2 t2 = *reinterpret_cast<const uint2*>(dirs + (r * 64 + lane) * 2); ck.d[k].x = t2.x; ck.d[k].z = t2.y; }
+                } else {
+                    const int rr = r - rows_lds;
+                    if (WIDE) ck.d[k] = *reinterpret_cast<const uint4*>(spill + (rr * 64 + lane) * 4);
+                    else { const uint2 t2 = *reinterpret_cast<const uint2*>(spill + (rr * 64 + lane) * 2); ck.d[k].x = t2.x; ck.d[k].z = t2.y; }
+                }
+                const int b = brow[r * bstep];
+                ck.b[k] = b > SA_PAD_CODE ? SA_PAD_CODE : b;
+            }
+        }
+    };
+
+    auto process = [&](int ch, const SaChunk& ck) {
+        uint64_t e[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) e[k] = (MODE == SA_MODE_TRI) ? emask[ck.b[k]] : 0;
+        uint32_t packed = 0;
+#pragma unroll
+        for (int k = 3; k >= 0; k--) {
+            const int r = 4 * ch + k;
+            if (r < lenq) {
+                PT A, B;
+                if (WIDE) {
+                    A = (PT)(((uint64_t)ck.d[k].x << nhi) | (ck.d[k].y & himask));
+                    B = (PT)(((uint64_t)ck.d[k].z << nhi) | (ck.d[k].w & himask));
+                } else {
+                    A = (PT)ck.d[k].x;
+                    B = (PT)ck.d[k].z;
+                }
+                int run = 0;
+                if (j > 0) {
+                    const PT x = (PT) ~((A & B) >> (ncols - j));          // zero bit = first column that is not LEFT
+                    if (WIDE) run = x ? __builtin_ctzll((uint64_t)x) : 64;
+                    else run = x ? __builtin_ctz((uint32_t)x) : 32;
+                    run = min(run, j);
+                    j -= run;
+                }
+                int t = 1;                                               // left border: UP
+                if (j > 0) t = (int)((A >> (ncols - j)) & 1);            // 0 = DIAG, 1 = UP
+                if (t == 0) {
+                    const int c = j - 1;
+                    if (MODE == SA_MODE_TRI) matches += (int)((e[k] >> c) & 1);
+                    else matches += ((int)acol[c] == ck.b[k]) ? 1 : 0;
+                    j--;
+                }
+                gaps += t;
+                packed |= (uint32_t)(run * 2 + t) << (8 * k);
+            }
+        }
+        stage_rec[2 + ch] = packed;
+    };
+
+    SaChunk c0, c1;
+    int ch = (maxlen - 1) >> 2;
+    load_chunk(ch, c0);
+    for (; ch >= 0; ch -= 2) {
+        if (ch > 0) load_chunk(ch - 1, c1);
+        process(ch, c0);
+        if (ch > 0) {
+            if (ch > 1) load_chunk(ch - 2, c0);
+            process(ch - 1, c1);
+        }
+    }
+    matches_out = matches;
+    gaps_out = gaps;
 }
 
 template <int MODE>
@@ -116,6 +268,11 @@ __global__ void __launch_bounds__(64, 2) sa_peptide_kernel(const SaPepParams P) 
     const int lane = threadIdx.x;
     uint32_t* const spill = P.spill + (size_t)blockIdx.x * P.spill_rows * 256;
     const uint32_t cpr = P.stride >> 4;   // 16-byte chunks per record
+    // optional phase timers (diagnostic builds of the caller pass a buffer): 0 fetch, 1 profile, 2 operands, 3 fill, 4 traceback, 5 store
+    const bool timed = P.phase_cycles != nullptr;
+    unsigned long long tph[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long tmark = timed ? __builtin_amdgcn_s_memtime() : 0;
+#define SA_PHASE(k) do { if (timed) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tph[k] += t_ - tmark; tmark = t_; } } while (0)
 
     if (MODE == SA_MODE_ADJ) {
         // LDS copy of S' laid out [b][a] so that a row residue selects a 128-byte row
@@ -132,6 +289,7 @@ __global__ void __launch_bounds__(64, 2) sa_peptide_kernel(const SaPepParams P) 
         it = __builtin_amdgcn_readfirstlane(it);
         if (it >= P.nitems) break;
         const SaItem item = P.items[it];
+        SA_PHASE(0);
 
         int a4[SA_LP];          // ADJACENT: byte offset of column residue inside a table row
         int lenp_u = 0;         // TRIANGULAR: length of the shared first sequence
@@ -143,8 +301,8 @@ __global__ void __launch_bounds__(64, 2) sa_peptide_kernel(const SaPepParams P) 
             const int a = P.codes_fo[(size_t)p * SA_LP + lane];
             __syncthreads();   // previous item's readers are done with prof/emask
 #pragma unroll
-            for (int b = 0; b < 20; b++) prof[b * SA_LP + lane] = P.sprime[a * SA_SPRIME_STRIDE + b];
-            prof[20 * SA_LP + lane] = 0;
+            for (int b = 0; b < 20; b++) prof[b * SA_PROF_STRIDE + lane] = P.sprime[a * SA_SPRIME_STRIDE + b];
+            prof[20 * SA_PROF_STRIDE + lane] = 0;
 #pragma unroll
             for (int b = 0; b < 20; b++) {
                 const uint64_t mk = __ballot(a == b);
@@ -163,10 +321,11 @@ __global__ void __launch_bounds__(64, 2) sa_peptide_kernel(const SaPepParams P) 
             ntasks = 1;
         }
 
+        SA_PHASE(1);
         for (uint32_t task = 0; task < ntasks; task++) {
             // ---------------------------------------------------------- operands
             bool active;
-            int lenq, lenp, maxlen, g0;
+            int lenq, lenp, maxlen, gend;
             uint32_t rel;                 // record index relative to out_row
             const uint8_t* brow;          // row residue r of this lane at brow[r * bstep]
             int bstep;
@@ -180,7 +339,7 @@ __global__ void __launch_bounds__(64, 2) sa_peptide_kernel(const SaPepParams P) 
                 lenq = active ? P.tile_len[q] : 0;
                 lenp = lenp_u;
                 maxlen = P.tile_maxlen[tile];
-                g0 = (SA_LP - lenp_u) >> 2;
+                gend = (lenp_u + 3) >> 2;
                 rel = fiq - item.p - 1;
                 brow = P.tiles + (size_t)tile * 4096 + lane;
                 bstep = 64;
@@ -191,10 +350,10 @@ __global__ void __launch_bounds__(64, 2) sa_peptide_kernel(const SaPepParams P) 
                 lenp = P.len_fo[s1];
                 lenq = active ? P.len_fo[s2] : 0;
                 maxlen = __builtin_amdgcn_readfirstlane(wave_max(lenq));
-                g0 = __builtin_amdgcn_readfirstlane(wave_min(SA_LP - lenp)) >> 2;
+                gend = (__builtin_amdgcn_readfirstlane(wave_max(lenp)) + 3) >> 2;
                 rel = lane;
                 acol = P.codes_fo + (size_t)s1 * SA_LP;
-                brow = P.codes_fo + (size_t)s2 * SA_LP + (SA_LP - P.len_fo[s2]);
+                brow = P.codes_fo + (size_t)s2 * SA_LP;
                 bstep = 1;
                 const uint32_t* aw = reinterpret_cast<const uint32_t*>(acol);
 #pragma unroll
@@ -206,142 +365,87 @@ __global__ void __launch_bounds__(64, 2) sa_peptide_kernel(const SaPepParams P) 
                     a4[4 * w + 3] = (v >> 24) << 2;
                 }
             }
-            const bool wide = g0 < 8;                       // columns 0..31 in use: four plane words per row
+            const bool wide = gend > 8;                     // more than 32 columns: four plane words per row
             const int wpr = wide ? 4 : 2;                   // dwords per direction row per lane
             const int rows_lds = (int)(P.lds_dir_bytes / (uint32_t)(wpr * 256));
 
+            SA_PHASE(2);
             // -------------------------------------------------------------- fill
             int R[SA_LP], Q[SA_LP];
 #pragma unroll
             for (int c = 0; c < SA_LP; c++) { R[c] = 0; Q[c] = 0; }
             uint32_t alo = 0, ahi = 0, blo = 0, bhi = 0;
 
-            int b0 = brow[0];                               // residue of row 0 (pad code if none)
-            int b1 = (1 < maxlen) ? brow[bstep] : SA_PAD_CODE;
-            if (MODE == SA_MODE_TRI) { if (!active) { b0 = SA_PAD_CODE; b1 = SA_PAD_CODE; } }
-            else { if (b0 > SA_PAD_CODE) b0 = SA_PAD_CODE; if (b1 > SA_PAD_CODE) b1 = SA_PAD_CODE; }
-            int4 sc;
-            auto first_scores = [&](int b) {
-                if (MODE == SA_MODE_TRI) {
-                    sc = *reinterpret_cast<const int4*>(prof + b * SA_LP + 4 * g0);
-                } else {
-                    const char* rb = reinterpret_cast<const char*>(prof + (b < 20 ? b : 0) * 32);
-                    // first active group is wave-uniform, the register index must be static
-#pragma unroll
-                    for (int g = 0; g < SA_LP / 4; g++) {
-                        if (g == g0) {
-                            sc.x = *reinterpret_cast<const int32_t*>(rb + a4[4 * g + 0]);
-                            sc.y = *reinterpret_cast<const int32_t*>(rb + a4[4 * g + 1]);
-                            sc.z = *reinterpret_cast<const int32_t*>(rb + a4[4 * g + 2]);
-                            sc.w = *reinterpret_cast<const int32_t*>(rb + a4[4 * g + 3]);
-                        }
-                    }
-                }
+            auto residue = [&](int r) -> int {
+                int b = (r < maxlen) ? (int)brow[r * bstep] : SA_PAD_CODE;
+                if (MODE == SA_MODE_TRI) return active ? b : SA_PAD_CODE;
+                return b > SA_PAD_CODE ? SA_PAD_CODE : b;
             };
-            first_scores(b0);
-
             auto store_dirs = [&](int r) {
                 if (r < rows_lds) {
                     if (wide) *reinterpret_cast<uint4*>(dirs + (r * 64 + lane) * 4) = make_uint4(alo, ahi, blo, bhi);
-                    else *reinterpret_cast<uint2*>(dirs + (r * 64 + lane) * 2) = make_uint2(ahi, bhi);
+                    else *reinterpret_cast<uint2*>(dirs + (r * 64 + lane) * 2) = make_uint2(alo, blo);
                 } else {
                     const int rr = r - rows_lds;
                     if (wide) *reinterpret_cast<uint4*>(spill + (rr * 64 + lane) * 4) = make_uint4(alo, ahi, blo, bhi);
-                    else *reinterpret_cast<uint2*>(spill + (rr * 64 + lane) * 2) = make_uint2(ahi, bhi);
+                    else *reinterpret_cast<uint2*>(spill + (rr * 64 + lane) * 2) = make_uint2(alo, blo);
                 }
             };
 
-            for (int r = 0; r < maxlen; r += 2) {
-                // residues two rows ahead (latency hidden behind two rows of arithmetic)
-                int b2 = (r + 2 < maxlen) ? brow[(r + 2) * bstep] : SA_PAD_CODE;
-                int b3 = (r + 3 < maxlen) ? brow[(r + 3) * bstep] : SA_PAD_CODE;
-                if (MODE == SA_MODE_ADJ) { if (b2 > SA_PAD_CODE) b2 = SA_PAD_CODE; if (b3 > SA_PAD_CODE) b3 = SA_PAD_CODE; }
-                const int32_t* base0;
-                const int32_t* base1;
-                const int32_t* base2;
-                if (MODE == SA_MODE_TRI) {
-                    base0 = prof + b0 * SA_LP; base1 = prof + b1 * SA_LP; base2 = prof + b2 * SA_LP;
-                } else {
-                    base0 = prof + (b0 < 20 ? b0 : 0) * 32;
-                    base1 = prof + (b1 < 20 ? b1 : 0) * 32;
-                    base2 = prof + (b2 < 20 ? b2 : 0) * 32;
+            int b0 = residue(0), b1 = residue(1);
+            if (MODE == SA_MODE_TRI) {
+                int4 sc0 = *reinterpret_cast<const int4*>(prof + b0 * SA_PROF_STRIDE);
+                for (int r = 0; r < maxlen; r += 2) {
+                    // residues two rows ahead: their latency is covered by two rows of arithmetic
+                    const int b2 = residue(r + 2), b3 = residue(r + 3);
+                    if (r < lenq) {
+                        fill_row_tri(R, Q, gend, prof + b0 * SA_PROF_STRIDE, prof + b1 * SA_PROF_STRIDE, sc0,
+                                     alo, ahi, blo, bhi);
+                        store_dirs(r);
+                    }
+                    if (r + 1 < lenq) {
+                        fill_row_tri(Q, R, gend, prof + b1 * SA_PROF_STRIDE, prof + b2 * SA_PROF_STRIDE, sc0,
+                                     alo, ahi, blo, bhi);
+                        store_dirs(r + 1);
+                    }
+                    b0 = b2; b1 = b3;
                 }
-                if (r < lenq) {
-                    fill_row<MODE>(R, Q, g0, base0, base1, a4, sc, alo, ahi, blo, bhi);
-                    store_dirs(r);
+            } else {
+                for (int r = 0; r < maxlen; r += 2) {
+                    const int b2 = residue(r + 2), b3 = residue(r + 3);
+                    if (r < lenq) {
+                        fill_row_adj(R, Q, gend, prof + (b0 < 20 ? b0 : 0) * 32, a4, alo, ahi, blo, bhi);
+                        store_dirs(r);
+                    }
+                    if (r + 1 < lenq) {
+                        fill_row_adj(Q, R, gend, prof + (b1 < 20 ? b1 : 0) * 32, a4, alo, ahi, blo, bhi);
+                        store_dirs(r + 1);
+                    }
+                    b0 = b2; b1 = b3;
                 }
-                if (MODE == SA_MODE_ADJ) first_scores(b1);
-                if (r + 1 < lenq) {
-                    fill_row<MODE>(Q, R, g0, base1, base2, a4, sc, alo, ahi, blo, bhi);
-                    store_dirs(r + 1);
-                }
-                if (MODE == SA_MODE_ADJ) first_scores(b2);
-                b0 = b2; b1 = b3;
             }
-            const int dlast = (lenq & 1) ? Q[SA_LP - 1] : R[SA_LP - 1];
+            int dlast;
+            if (MODE == SA_MODE_TRI) {
+                const int dq = pick_column(Q, lenp - 1), dr = pick_column(R, lenp - 1);
+                dlast = (lenq & 1) ? dq : dr;
+            } else {
+                dlast = 0;
+#pragma unroll
+                for (int c = 0; c < SA_LP; c++)
+                    if (c == lenp - 1) dlast = (lenq & 1) ? Q[c] : R[c];
+            }
             const int score = dlast + (lenp + lenq) * P.gap;
             __syncthreads();   // direction rows written by this wave are visible to its loads
 
-            // --------------------------------------------------------- traceback
-            // One step per row, bottom row first.  The direction words of row r-1,
-            // the row residue of row r-2 and the equality mask of row r-1 are
-            // requested while row r is being processed.
-            int j = lenp, matches = 0, gaps = 0;
-            uint32_t acc = 0;
-            const int padl = SA_LP - lenp;
-            auto load_dirs = [&](int r) -> uint4 {
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (r < rows_lds) {
-                    if (wide) v = *reinterpret_cast<const uint4*>(dirs + (r * 64 + lane) * 4);
-                    else { const uint2 t2 = *reinterpret_cast<const uint2*>(dirs + (r * 64 + lane) * 2); v.y = t2.x; v.w = t2.y; }
-                } else {
-                    const int rr = r - rows_lds;
-                    if (wide) v = *reinterpret_cast<const uint4*>(spill + (rr * 64 + lane) * 4);
-                    else { const uint2 t2 = *reinterpret_cast<const uint2*>(spill + (rr * 64 + lane) * 2); v.y = t2.x; v.w = t2.y; }
-                }
-                return v;
-            };
-            auto load_res = [&](int r) -> int {
-                int b = (r >= 0) ? (int)brow[r * bstep] : SA_PAD_CODE;
-                return b > SA_PAD_CODE ? SA_PAD_CODE : b;
-            };
-            uint4 dcur = load_dirs(maxlen - 1);
-            int bcur = load_res(maxlen - 1);
-            int bnxt = load_res(maxlen - 2);
-            uint64_t ecur = (MODE == SA_MODE_TRI) ? emask[bcur] : 0;
-            for (int r = maxlen - 1; r >= 0; --r) {
-                uint4 dnxt = make_uint4(0, 0, 0, 0);
-                if (r > 0) dnxt = load_dirs(r - 1);
-                const int bnn = load_res(r - 2);
-                const uint64_t enxt = (MODE == SA_MODE_TRI) ? emask[bnxt] : 0;
-                if (r < lenq) {
-                    const uint64_t A = ((uint64_t)dcur.x << 32) | dcur.y;   // bit (63-c): cell != diag + S'
-                    const uint64_t B = ((uint64_t)dcur.z << 32) | dcur.w;   // bit (63-c): cell != up
-                    int run = 0;
-                    if (j > 0) {
-                        const uint64_t x = ~((A & B) >> (lenp - j));        // zero bit = first non-LEFT column
-                        run = x ? __builtin_ctzll(x) : 64;
-                        run = min(run, j);
-                        j -= run;
-                    }
-                    int t = 1;                                              // left border: UP
-                    if (j > 0) t = (int)((A >> (lenp - j)) & 1);            // 0 = DIAG, 1 = UP
-                    if (t == 0) {
-                        const int c = padl + j - 1;
-                        if (MODE == SA_MODE_TRI) matches += (int)((ecur >> c) & 1);
-                        else matches += ((int)acol[c] == bcur) ? 1 : 0;
-                        j--;
-                    }
-                    gaps += t;
-                    const int k = lenq - 1 - r;
-                    acc |= (uint32_t)(run * 2 + t) << (8 * (k & 3));
-                    if ((k & 3) == 3 || r == 0) {
-                        stage[lane * SA_LDS_STAGE_DWORDS + 2 + (k >> 2)] = acc;
-                        acc = 0;
-                    }
-                }
-                dcur = dnxt; bcur = bnxt; bnxt = bnn; ecur = enxt;
-            }
+            SA_PHASE(3);
+            int matches = 0, gaps = 0;
+            if (wide)
+                traceback<MODE, uint64_t>(lane, maxlen, lenq, lenp, 4 * gend, rows_lds, dirs, spill, brow, bstep, acol, emask,
+                                          stage + lane * SA_LDS_STAGE_DWORDS, matches, gaps);
+            else
+                traceback<MODE, uint32_t>(lane, maxlen, lenq, lenp, 4 * gend, rows_lds, dirs, spill, brow, bstep, acol, emask,
+                                          stage + lane * SA_LDS_STAGE_DWORDS, matches, gaps);
+            SA_PHASE(4);
             stage[lane * SA_LDS_STAGE_DWORDS + 0] = (uint32_t)score;
             stage[lane * SA_LDS_STAGE_DWORDS + 1] = (uint32_t)matches | ((uint32_t)gaps << 16);
             __syncthreads();
@@ -357,8 +461,14 @@ __global__ void __launch_bounds__(64, 2) sa_peptide_kernel(const SaPepParams P) 
                 }
             }
             __syncthreads();   // staging area is reused by the next task
+            SA_PHASE(5);
         }
     }
+    if (timed && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) P.phase_cycles[(size_t)blockIdx.x * 8 + k] = tph[k];
+    }
+#undef SA_PHASE
 }
 
 extern "C" void sa_launch_peptide(int mode, const SaPepParams* p, unsigned grid, unsigned lds_bytes,

@@ -1,0 +1,42 @@
+"""Synthetic peptide / protein sets, reproducible from a seed without any data file.
+
+One splitmix64 stream per set; per sequence: len = lo + next() % (hi - lo + 1),
+each residue ALPHABET[next() % 20], label = next() & 1.  The same recipe is
+implemented in C by the host tool (tools/sa_synth.c) so both produce the same file.
+"""
+import numpy as np
+
+ALPHABET = b"ARNDCQEGHILKMFPSTWYV"
+_GOLDEN = np.uint64(0x9E3779B97F4A7C15)
+
+
+def _splitmix64_block(seed, start, count):
+    """Outputs number start .. start+count-1 (0-based) of splitmix64(seed)."""
+    with np.errstate(over="ignore"):
+        k = np.arange(start + 1, start + count + 1, dtype=np.uint64)
+        z = np.uint64(seed) + k * _GOLDEN
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def generate(n, lo, hi, seed):
+    """Returns (list of bytes sequences, list of int labels)."""
+    total_max = n * (hi + 2)
+    draws = _splitmix64_block(seed, 0, total_max)
+    residues = np.frombuffer(ALPHABET, dtype=np.uint8)[(draws % np.uint64(20)).astype(np.int64)]
+    span = np.uint64(hi - lo + 1)
+    seqs, labels = [], []
+    pos = 0
+    for _ in range(n):
+        ln = lo + int(draws[pos] % span)
+        seqs.append(residues[pos + 1 : pos + 1 + ln].tobytes())
+        labels.append(int(draws[pos + 1 + ln] & np.uint64(1)))
+        pos += ln + 2
+    return seqs, labels
+
+
+def write_csv(path, seqs, labels):
+    with open(path, "wb") as f:
+        f.write(b"sequence,label\n")
+        f.write(b"".join(s + b"," + str(l).encode() + b"\n" for s, l in zip(seqs, labels)))
