@@ -159,12 +159,13 @@ __device__ __forceinline__ int pick_column(const int (&BANK)[SA_LP], const int c
 }
 
 // ---------------------------------------------------------------- traceback
-// Bottom row first, four rows per step of the outer loop so that the loads of a
-// whole chunk (direction words from LDS or from the spill area, row residues)
-// are in flight together and one chunk ahead of their use.  A row shifted
-// ncols = 4*gend direction bits into each plane, so column c sits at bit
-// (ncols-1-c): plane A says "cell != diag + S'", plane B "cell != up".  PT is
-// uint32_t when ncols <= 32 (one word per plane) and uint64_t otherwise.
+// Bottom row first, four rows per chunk.  The loads of a chunk (direction words
+// from LDS or from the spill area, row residues) are issued two chunks ahead of
+// their use.  A row shifted ncols = 4*gend direction bits into each plane, so
+// column c sits at bit (ncols-1-c): plane A says "cell != diag + S'", plane B
+// "cell != up".  PT is uint32_t when ncols <= 32 (one word per plane) and
+// uint64_t otherwise.  Rows r >= split live in LDS (slot r - split), the rows
+// before them in the spill area.
 struct SaChunk {
     uint4 d[4];
     int b[4];
@@ -172,34 +173,34 @@ struct SaChunk {
 
 template <int MODE, typename PT>
 __device__ __forceinline__ void traceback(const int lane, const int maxlen, const int lenq, const int lenp,
-                                          const int ncols, const int rows_lds, const uint32_t* __restrict__ dirs,
+                                          const int ncols, const int split, const uint32_t* __restrict__ dirs,
                                           const uint32_t* __restrict__ spill, const uint8_t* __restrict__ brow,
                                           const int bstep, const uint8_t* __restrict__ acol,
                                           const uint64_t* __restrict__ emask, uint32_t* __restrict__ stage_rec,
                                           int& matches_out, int& gaps_out) {
     constexpr bool WIDE = sizeof(PT) == 8;
+    constexpr int PBITS = WIDE ? 63 : 31;
     int j = lenp, matches = 0, gaps = 0;
     const int nhi = ncols - 32;                              // WIDE: columns held by the second word
     const uint32_t himask = WIDE ? (uint32_t)((1ull << nhi) - 1) : 0;
 
+    // Nothing loaded here is used before process(): every request of a chunk (and
+    // of the two chunks after it) is in flight at once.  Row indices past the end
+    // of the tile are clamped, so the requests need no guard.
     auto load_chunk = [&](int ch, SaChunk& ck) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const int r = 4 * ch + k;
+            const int r = min(4 * ch + k, maxlen - 1);   // wave-uniform
             ck.d[k] = make_uint4(0, 0, 0, 0);
-            ck.b[k] = SA_PAD_CODE;
-            if (r < maxlen) {   // wave-uniform
-                if (r < rows_lds) {
-                    if (WIDE) ck.d[k] = *reinterpret_cast<const uint4*>(dirs + (r * 64 + lane) * 4);
-                    else { const uint2 t2 = *reinterpret_cast<const uint2*>(dirs + (r * 64 + lane) * 2); ck.d[k].x = t2.x; ck.d[k].z = t2.y; }
-                } else {
-                    const int rr = r - rows_lds;
-                    if (WIDE) ck.d[k] = *reinterpret_cast<const uint4*>(spill + (rr * 64 + lane) * 4);
-                    else { const uint2 t2 = *reinterpret_cast<const uint2*>(spill + (rr * 64 + lane) * 2); ck.d[k].x = t2.x; ck.d[k].z = t2.y; }
-                }
-                const int b = brow[r * bstep];
-                ck.b[k] = b > SA_PAD_CODE ? SA_PAD_CODE : b;
+            if (r >= split) {
+                const int rr = r - split;
+                if (WIDE) ck.d[k] = *reinterpret_cast<const uint4*>(dirs + (rr * 64 + lane) * 4);
+                else { const uint2 t2 = *reinterpret_cast<const uint2*>(dirs + (rr * 64 + lane) * 2); ck.d[k].x = t2.x; ck.d[k].z = t2.y; }
+            } else {
+                if (WIDE) ck.d[k] = *reinterpret_cast<const uint4*>(spill + (r * 64 + lane) * 4);
+                else { const uint2 t2 = *reinterpret_cast<const uint2*>(spill + (r * 64 + lane) * 2); ck.d[k].x = t2.x; ck.d[k].z = t2.y; }
             }
+            ck.b[k] = brow[r * bstep];                   // residue codes are <= SA_PAD_CODE everywhere
         }
     };
 
@@ -220,22 +221,22 @@ __device__ __forceinline__ void traceback(const int lane, const int maxlen, cons
                     A = (PT)ck.d[k].x;
                     B = (PT)ck.d[k].z;
                 }
-                int run = 0;
-                if (j > 0) {
-                    const PT x = (PT) ~((A & B) >> (ncols - j));          // zero bit = first column that is not LEFT
-                    if (WIDE) run = x ? __builtin_ctzll((uint64_t)x) : 64;
-                    else run = x ? __builtin_ctz((uint32_t)x) : 32;
-                    run = min(run, j);
-                    j -= run;
-                }
-                int t = 1;                                               // left border: UP
-                if (j > 0) t = (int)((A >> (ncols - j)) & 1);            // 0 = DIAG, 1 = UP
-                if (t == 0) {
-                    const int c = j - 1;
-                    if (MODE == SA_MODE_TRI) matches += (int)((e[k] >> c) & 1);
-                    else matches += ((int)acol[c] == ck.b[k]) ? 1 : 0;
-                    j--;
-                }
+                // branch-free: with j == 0 the shifted values are meaningless and overridden
+                const PT x = (PT) ~((A & B) >> ((ncols - j) & PBITS));    // zero bit = first column that is not LEFT
+                int run;
+                if (WIDE) run = x ? __builtin_ctzll((uint64_t)x) : 64;
+                else run = x ? __builtin_ctz((uint32_t)x) : 32;
+                run = min(run, j);
+                j -= run;
+                const int bit = (int)((A >> ((ncols - j) & PBITS)) & 1);
+                const int t = (j > 0) ? bit : 1;                          // 0 = DIAG, 1 = UP (left border: UP)
+                const int dg = t ^ 1;
+                const int c = (j - 1) & 63;
+                int eq;
+                if (MODE == SA_MODE_TRI) eq = WIDE ? (int)((e[k] >> c) & 1) : (int)(((uint32_t)e[k] >> (c & 31)) & 1);
+                else eq = (t == 0 && (int)acol[c] == ck.b[k]) ? 1 : 0;
+                matches += eq & dg;
+                j -= dg;
                 gaps += t;
                 packed |= (uint32_t)(run * 2 + t) << (8 * k);
             }
@@ -243,15 +244,20 @@ __device__ __forceinline__ void traceback(const int lane, const int maxlen, cons
         stage_rec[2 + ch] = packed;
     };
 
-    SaChunk c0, c1;
+    SaChunk c0, c1, c2;
     int ch = (maxlen - 1) >> 2;
     load_chunk(ch, c0);
-    for (; ch >= 0; ch -= 2) {
-        if (ch > 0) load_chunk(ch - 1, c1);
+    if (ch > 0) load_chunk(ch - 1, c1);
+    for (; ch >= 0; ch -= 3) {
+        if (ch > 1) load_chunk(ch - 2, c2);
         process(ch, c0);
         if (ch > 0) {
-            if (ch > 1) load_chunk(ch - 2, c0);
+            if (ch > 2) load_chunk(ch - 3, c0);
             process(ch - 1, c1);
+        }
+        if (ch > 1) {
+            if (ch > 3) load_chunk(ch - 4, c1);
+            process(ch - 2, c2);
         }
     }
     matches_out = matches;
@@ -368,6 +374,7 @@ __global__ void __launch_bounds__(64, 2) sa_peptide_kernel(const SaPepParams P) 
             const bool wide = gend > 8;                     // more than 32 columns: four plane words per row
             const int wpr = wide ? 4 : 2;                   // dwords per direction row per lane
             const int rows_lds = (int)(P.lds_dir_bytes / (uint32_t)(wpr * 256));
+            const int split = max(0, maxlen - rows_lds);    // rows >= split stay in LDS, earlier rows go to the spill area
 
             SA_PHASE(2);
             // -------------------------------------------------------------- fill
@@ -376,19 +383,16 @@ __global__ void __launch_bounds__(64, 2) sa_peptide_kernel(const SaPepParams P) 
             for (int c = 0; c < SA_LP; c++) { R[c] = 0; Q[c] = 0; }
             uint32_t alo = 0, ahi = 0, blo = 0, bhi = 0;
 
-            auto residue = [&](int r) -> int {
-                int b = (r < maxlen) ? (int)brow[r * bstep] : SA_PAD_CODE;
-                if (MODE == SA_MODE_TRI) return active ? b : SA_PAD_CODE;
-                return b > SA_PAD_CODE ? SA_PAD_CODE : b;
-            };
+            // rows past the end of a sequence read padding (tiles and slots are 64 positions long)
+            auto residue = [&](int r) -> int { return (int)brow[min(r, SA_LP - 1) * bstep]; };
             auto store_dirs = [&](int r) {
-                if (r < rows_lds) {
-                    if (wide) *reinterpret_cast<uint4*>(dirs + (r * 64 + lane) * 4) = make_uint4(alo, ahi, blo, bhi);
-                    else *reinterpret_cast<uint2*>(dirs + (r * 64 + lane) * 2) = make_uint2(alo, blo);
+                if (r >= split) {
+                    const int rr = r - split;
+                    if (wide) *reinterpret_cast<uint4*>(dirs + (rr * 64 + lane) * 4) = make_uint4(alo, ahi, blo, bhi);
+                    else *reinterpret_cast<uint2*>(dirs + (rr * 64 + lane) * 2) = make_uint2(alo, blo);
                 } else {
-                    const int rr = r - rows_lds;
-                    if (wide) *reinterpret_cast<uint4*>(spill + (rr * 64 + lane) * 4) = make_uint4(alo, ahi, blo, bhi);
-                    else *reinterpret_cast<uint2*>(spill + (rr * 64 + lane) * 2) = make_uint2(alo, blo);
+                    if (wide) *reinterpret_cast<uint4*>(spill + (r * 64 + lane) * 4) = make_uint4(alo, ahi, blo, bhi);
+                    else *reinterpret_cast<uint2*>(spill + (r * 64 + lane) * 2) = make_uint2(alo, blo);
                 }
             };
 
@@ -440,10 +444,10 @@ __global__ void __launch_bounds__(64, 2) sa_peptide_kernel(const SaPepParams P) 
             SA_PHASE(3);
             int matches = 0, gaps = 0;
             if (wide)
-                traceback<MODE, uint64_t>(lane, maxlen, lenq, lenp, 4 * gend, rows_lds, dirs, spill, brow, bstep, acol, emask,
+                traceback<MODE, uint64_t>(lane, maxlen, lenq, lenp, 4 * gend, split, dirs, spill, brow, bstep, acol, emask,
                                           stage + lane * SA_LDS_STAGE_DWORDS, matches, gaps);
             else
-                traceback<MODE, uint32_t>(lane, maxlen, lenq, lenp, 4 * gend, rows_lds, dirs, spill, brow, bstep, acol, emask,
+                traceback<MODE, uint32_t>(lane, maxlen, lenq, lenp, 4 * gend, split, dirs, spill, brow, bstep, acol, emask,
                                           stage + lane * SA_LDS_STAGE_DWORDS, matches, gaps);
             SA_PHASE(4);
             stage[lane * SA_LDS_STAGE_DWORDS + 0] = (uint32_t)score;

@@ -24,3 +24,4 @@ for sched, name, nrows in ((sa.ADJACENT, 'adjacent', None), (sa.TRIANGULAR, 'tri
             if bad <= 5:
                 print('MISMATCH', name, k, i, j, seqs[i], seqs[j], a1, a2, st and (st.score, st.matches, st.gaps), 'oracle', o1, o2, o.score, o.matches, o.gaps, bytes(rec[k][:24]).hex())
     print(name, 'pairs', len(pairs), 'bad', bad, flush=True)
+    if bad: sys.exit(1)
