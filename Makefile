@@ -10,13 +10,17 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Wall -Wno-unused-functi
 .PHONY: all lib oracle clean
 all: lib oracle
 
-lib: $(LIB)
-$(LIB): $(CSRC)/sa_kernels.hip $(CSRC)/sa_api.cpp $(CSRC)/sa_device.h include/sa_hip.h
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/sa_kernels.hip $(CSRC)/sa_api.cpp
+MAIN    := sequencealigner_amd/sa_main
+
+lib: $(LIB) $(MAIN)
+$(MAIN): $(CSRC)/sa_main.cpp $(LIB)
+	$(HIPCC) -O2 -std=c++17 -Wall -o $@ $(CSRC)/sa_main.cpp -Lsequencealigner_amd -lsa_hip -Wl,-rpath,'$$ORIGIN'
+$(LIB): $(CSRC)/sa_kernels.hip $(CSRC)/sa_api.cpp $(CSRC)/sa_host.cpp $(CSRC)/sa_device.h include/sa_hip.h include/sa_host.h
+	$(HIPCC) $(HIPFLAGS) -shared -pthread -o $@ $(CSRC)/sa_kernels.hip $(CSRC)/sa_api.cpp $(CSRC)/sa_host.cpp
 
 oracle:
 	$(MAKE) -C oracle all
 
 clean:
-	rm -f $(LIB)
+	rm -f $(LIB) $(MAIN)
 	$(MAKE) -C oracle clean

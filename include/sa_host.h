@@ -1,0 +1,68 @@
+/*
+ * sa_host.h -- the CSV-in / CSV-out driver above sa_hip.h, as a C ABI.
+ *
+ * sa_settings carries the reference's compile-time settings (include/user.h:7-75)
+ * as run-time values under the same names, in lower case; sa_settings_load reads
+ * them from a file of "#define NAME value" lines, i.e. from a user.h the
+ * reference's GUI has written (scripts/config_schema.py:201-241).  sa_run_csv is
+ * the reference's main() (src/main.c:7-134) with the worker pool replaced by the
+ * GPU library: parse -> dispatch -> format in pair order -> write.
+ */
+#ifndef SA_HOST_H
+#define SA_HOST_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+    char input_file[4096];            /* INPUT_FILE  (include/user.h:59) */
+    char output_file[4096];           /* OUTPUT_FILE (include/user.h:60) */
+    uint32_t max_csv_line;            /* MAX_CSV_LINE, informational: rows are not copied into fixed buffers */
+    uint32_t max_seq_len;             /* MAX_SEQ_LEN: sequences must be shorter than this (include/user.h:10) */
+    int32_t gap_penalty;              /* GAP_PENALTY (include/user.h:13) */
+    uint32_t read_csv_seq_pos;        /* READ_CSV_SEQ_POS */
+    uint32_t read_csv_cols;           /* READ_CSV_COLS */
+    char write_csv_header[1024];      /* WRITE_CSV_HEADER */
+    uint32_t write_csv_seq1_pos;      /* WRITE_CSV_SEQ1_POS (sequence 2 follows it) */
+    uint32_t write_csv_score_pos;
+    uint32_t write_csv_align_pos;
+    uint32_t write_csv_matches_pos;
+    uint32_t write_csv_mismatches_pos;
+    uint32_t write_csv_gaps_pos;
+    uint32_t write_csv_similarity_pos;
+    char write_csv_align_fmt[128];    /* WRITE_CSV_ALIGN_FMT: two %s */
+    int32_t mode_write;               /* MODE_WRITE: 0 = align only (include/user.h:65, src/main.c:111-116) */
+    int32_t similarity_analysis;      /* SIMILARITY_ANALYSIS */
+    uint32_t batch_size;              /* BATCH_SIZE: rows per batch; one GPU submission covers 64 batches unless pairs_per_submit is set */
+    /* settings the reference does not have */
+    int32_t schedule;                 /* SA_SCHEDULE_ADJACENT (the reference's) or SA_SCHEDULE_TRIANGULAR */
+    int32_t num_devices;              /* GPUs to use, chunks are dealt to them in turn */
+    int32_t devices[8];
+    int32_t format_threads;           /* host threads that expand and format records; 0 = min(16, cores) */
+    uint64_t pairs_per_submit;        /* 0 = batch_size * 64 */
+} sa_settings;
+
+typedef struct {
+    uint64_t rows;                    /* sequences read */
+    uint64_t pairs;
+    uint64_t cells;                   /* sum of len1*len2 */
+    uint64_t bytes_written;
+    uint64_t chunks_done;
+    double seconds;                   /* first byte parsed -> last byte written, set-up excluded (src/main.c:30,129) */
+    char message[256];                /* error text when the return code is not 0 */
+} sa_run_report;
+
+void sa_settings_default(sa_settings* st);
+/* reads "#define NAME value" lines; unknown names are ignored; returns 0 or a negative code */
+int sa_settings_load(sa_settings* st, const char* path);
+/* the reference's checks on a settings file (scripts/config_schema.py:100-198); message receives the first problem */
+int sa_settings_validate(const sa_settings* st, char* message, uint32_t message_cap);
+int sa_run_csv(const sa_settings* st, sa_run_report* report);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -13,4 +13,10 @@ from ._lib import (  # noqa: F401
     lib_path,
     load_library,
     similarity_bp,
+    Settings,
+    RunReport,
+    default_settings,
+    load_settings,
+    validate_settings,
+    run_csv,
 )

@@ -37,6 +37,48 @@ class AlignmentStats(C.Structure):
     ]
 
 
+class Settings(C.Structure):
+    """Mirror of sa_settings (include/sa_host.h): the reference's user.h keys in lower case."""
+    _fields_ = [
+        ("input_file", C.c_char * 4096),
+        ("output_file", C.c_char * 4096),
+        ("max_csv_line", C.c_uint32),
+        ("max_seq_len", C.c_uint32),
+        ("gap_penalty", C.c_int32),
+        ("read_csv_seq_pos", C.c_uint32),
+        ("read_csv_cols", C.c_uint32),
+        ("write_csv_header", C.c_char * 1024),
+        ("write_csv_seq1_pos", C.c_uint32),
+        ("write_csv_score_pos", C.c_uint32),
+        ("write_csv_align_pos", C.c_uint32),
+        ("write_csv_matches_pos", C.c_uint32),
+        ("write_csv_mismatches_pos", C.c_uint32),
+        ("write_csv_gaps_pos", C.c_uint32),
+        ("write_csv_similarity_pos", C.c_uint32),
+        ("write_csv_align_fmt", C.c_char * 128),
+        ("mode_write", C.c_int32),
+        ("similarity_analysis", C.c_int32),
+        ("batch_size", C.c_uint32),
+        ("schedule", C.c_int32),
+        ("num_devices", C.c_int32),
+        ("devices", C.c_int32 * 8),
+        ("format_threads", C.c_int32),
+        ("pairs_per_submit", C.c_uint64),
+    ]
+
+
+class RunReport(C.Structure):
+    _fields_ = [
+        ("rows", C.c_uint64),
+        ("pairs", C.c_uint64),
+        ("cells", C.c_uint64),
+        ("bytes_written", C.c_uint64),
+        ("chunks_done", C.c_uint64),
+        ("seconds", C.c_double),
+        ("message", C.c_char * 256),
+    ]
+
+
 _lib = None
 
 # every entry point include/sa_hip.h declares: name -> (restype, argtypes)
@@ -68,6 +110,11 @@ SIGNATURES = {
     "sa_debug_phase_cycles": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]),
     "sa_similarity_bp": (C.c_int, [C.c_int32, C.c_int32]),
     "sa_default_matrix": (None, [C.POINTER(C.c_int32)]),
+    # include/sa_host.h
+    "sa_settings_default": (None, [C.POINTER(Settings)]),
+    "sa_settings_load": (C.c_int, [C.POINTER(Settings), C.c_char_p]),
+    "sa_settings_validate": (C.c_int, [C.POINTER(Settings), C.c_char_p, C.c_uint32]),
+    "sa_run_csv": (C.c_int, [C.POINTER(Settings), C.POINTER(RunReport)]),
 }
 
 
@@ -95,6 +142,42 @@ def _check(rc):
 
 def similarity_bp(matches, columns):
     return load_library().sa_similarity_bp(matches, columns)
+
+
+def default_settings():
+    st = Settings()
+    load_library().sa_settings_default(C.byref(st))
+    return st
+
+
+def load_settings(path):
+    """Settings from a file of '#define NAME value' lines (a user.h written by the reference's GUI)."""
+    st = default_settings()
+    _check(load_library().sa_settings_load(C.byref(st), os.fsencode(path)))
+    return st
+
+
+def validate_settings(st):
+    msg = C.create_string_buffer(256)
+    rc = load_library().sa_settings_validate(C.byref(st), msg, 256)
+    return rc, msg.value.decode()
+
+
+def run_csv(input_file, output_file, schedule=ADJACENT, settings=None, **overrides):
+    """CSV in -> CSV out on the GPU(s); returns the RunReport.  Mirrors the reference's main()."""
+    st = settings if settings is not None else default_settings()
+    st.input_file = os.fsencode(input_file)
+    st.output_file = os.fsencode(output_file) if output_file else b""
+    st.schedule = schedule
+    if not output_file:
+        st.mode_write = 0
+    for k, v in overrides.items():
+        setattr(st, k, v)
+    rep = RunReport()
+    rc = load_library().sa_run_csv(C.byref(st), C.byref(rep))
+    if rc != 0:
+        raise SaError(rc, rep.message.decode() or load_library().sa_strerror(rc).decode())
+    return rep
 
 
 class Aligner:

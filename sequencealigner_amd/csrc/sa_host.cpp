@@ -1,0 +1,474 @@
+// sa_host.cpp -- the CSV-in / CSV-out program around the GPU library: settings,
+// ingest, chunked dispatch to one or more GPUs, record expansion, row
+// formatting and the ordered writer.  It restates the host side of the
+// reference's driver (src/main.c:7-134) with the worker pool replaced by
+// sa_submit / sa_next (include/sa_hip.h).
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cerrno>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/sa_hip.h"
+#include "../../include/sa_host.h"
+
+namespace {
+
+double now_s() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+struct Row {
+    const char* seq;
+    uint32_t len;
+    const char* other;      // first column that is not the sequence (what the reference prints, include/csv.h:91-95)
+    uint32_t other_len;
+};
+
+struct Table {
+    char* data = nullptr;
+    size_t size = 0;
+    int fd = -1;
+    std::vector<Row> rows;
+    ~Table() {
+        if (data && data != MAP_FAILED) munmap(data, size);
+        if (fd >= 0) close(fd);
+    }
+};
+
+// Rows of the input file.  Follows include/csv.h:28-36 (the first line is a
+// header and is skipped unconditionally) and include/csv.h:143-209 (leading
+// blanks / CR / LF skipped, fields split on ',', a row ends at CR, LF or NUL,
+// a missing final newline is fine).
+int load_table(const sa_settings* st, Table& t, std::string& err) {
+    t.fd = open(st->input_file, O_RDONLY);
+    if (t.fd < 0) { err = std::string("cannot open input file: ") + strerror(errno); return SA_ERR_ARG; }
+    struct stat sb;
+    if (fstat(t.fd, &sb) != 0) { err = "cannot stat input file"; return SA_ERR_ARG; }
+    t.size = (size_t)sb.st_size;
+    if (t.size == 0) return SA_OK;
+    t.data = (char*)mmap(nullptr, t.size, PROT_READ, MAP_PRIVATE, t.fd, 0);
+    if (t.data == MAP_FAILED) { err = "cannot map input file"; return SA_ERR_ARG; }
+    madvise(t.data, t.size, MADV_SEQUENTIAL);
+    const char* p = t.data;
+    const char* end = t.data + t.size;
+    while (p < end && *p != '\n') p++;
+    if (p < end) p++;
+    t.rows.reserve(t.size / 24 + 16);
+    while (p < end && *p) {
+        while (p < end && (*p == ' ' || *p == '\r' || *p == '\n')) p++;
+        if (p >= end || !*p) break;
+        Row r = {nullptr, 0, "", 0};
+        uint32_t col = 0;
+        bool have_other = false;
+        while (p < end && *p && *p != '\n' && *p != '\r') {
+            const char* f = p;
+            while (p < end && *p && *p != ',' && *p != '\n' && *p != '\r') p++;
+            if (col == st->read_csv_seq_pos) { r.seq = f; r.len = (uint32_t)(p - f); }
+            else if (!have_other) { r.other = f; r.other_len = (uint32_t)(p - f); have_other = true; }
+            if (p < end && *p == ',') { p++; col++; }
+        }
+        if (!r.seq) { r.seq = p; r.len = 0; }
+        t.rows.push_back(r);
+        while (p < end && (*p == '\n' || *p == '\r')) p++;
+    }
+    return SA_OK;
+}
+
+// Output layout: which output column shows what.  Restates init_format
+// (include/csv.h:38-82): the columns named by the WRITE_CSV_*_POS settings are
+// taken, the free ones are handed out in adjacent pairs to the pass-through
+// columns in order.
+struct Layout {
+    uint32_t ncols = 0;
+    std::vector<int> kind;      // per output column: K_* below
+    std::string part[3];        // alignment format split at its two "%s"
+};
+enum { K_NONE, K_SEQ1, K_SEQ2, K_SCORE, K_ALIGN, K_MATCHES, K_MISMATCHES, K_GAPS, K_SIMILARITY, K_OTHER1, K_OTHER2 };
+
+int make_layout(const sa_settings* st, Layout& L, std::string& err) {
+    const uint32_t sim = st->similarity_analysis ? 1 : 0;
+    L.ncols = 4 + (st->read_csv_cols - 1) * 2 + sim * 4;
+    L.kind.assign(L.ncols + 2, K_NONE);
+    auto take = [&](uint32_t pos, int kind) -> bool {
+        if (pos >= L.ncols || L.kind[pos] != K_NONE) return false;
+        L.kind[pos] = kind;
+        return true;
+    };
+    bool ok = take(st->write_csv_seq1_pos, K_SEQ1) && take(st->write_csv_seq1_pos + 1, K_SEQ2) &&
+              take(st->write_csv_score_pos, K_SCORE) && take(st->write_csv_align_pos, K_ALIGN);
+    if (sim)
+        ok = ok && take(st->write_csv_matches_pos, K_MATCHES) && take(st->write_csv_mismatches_pos, K_MISMATCHES) &&
+             take(st->write_csv_gaps_pos, K_GAPS) && take(st->write_csv_similarity_pos, K_SIMILARITY);
+    if (!ok) { err = "output column positions overlap or exceed the column count"; return SA_ERR_ARG; }
+    uint32_t idx = 0;
+    for (uint32_t i = 0; i + 1 < L.ncols && idx < st->read_csv_cols - 1; i++) {
+        if (L.kind[i] == K_NONE) {
+            L.kind[i] = K_OTHER1;
+            L.kind[i + 1] = K_OTHER2;
+            idx++;
+            i++;
+        }
+    }
+    const char* f = st->write_csv_align_fmt;
+    int part = 0;
+    const char* start = f;
+    while (*f) {
+        if (f[0] == '%' && f[1] == 's' && part < 2) {
+            L.part[part++] = std::string(start, f);
+            f += 2;
+            start = f;
+        } else {
+            f++;
+        }
+    }
+    L.part[part] = std::string(start, f);
+    if (part != 2) { err = "WRITE_CSV_ALIGN_FMT needs exactly two %s"; return SA_ERR_ARG; }
+    return SA_OK;
+}
+
+inline char* put_int(char* p, int v) {   // decimal text as include/fstring.h:25-55 produces it
+    char tmp[12];
+    int n = 0;
+    unsigned u = v < 0 ? 0u - (unsigned)v : (unsigned)v;
+    if (v < 0) *p++ = '-';
+    do { tmp[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+    while (n) *p++ = tmp[--n];
+    return p;
+}
+inline char* put_mem(char* p, const char* s, size_t n) { memcpy(p, s, n); return p + n; }
+
+// One output row; restates buffer_output (include/csv.h:85-140).
+size_t format_row(char* buf, const Layout& L, const Row& r1, const Row& r2, const char* a1, const char* a2,
+                  const sa_alignment_stats& s) {
+    char* p = buf;
+    for (uint32_t col = 0; col < L.ncols; col++) {
+        if (col) *p++ = ',';
+        switch (L.kind[col]) {
+            case K_OTHER1: p = put_mem(p, r1.other, r1.other_len); break;
+            case K_OTHER2: p = put_mem(p, r2.other, r2.other_len); break;
+            case K_SEQ1: p = put_mem(p, r1.seq, r1.len); break;
+            case K_SEQ2: p = put_mem(p, r2.seq, r2.len); break;
+            case K_SCORE: p = put_int(p, s.score); break;
+            case K_ALIGN:
+                p = put_mem(p, L.part[0].data(), L.part[0].size());
+                p = put_mem(p, a1, (size_t)s.columns);
+                p = put_mem(p, L.part[1].data(), L.part[1].size());
+                p = put_mem(p, a2, (size_t)s.columns);
+                p = put_mem(p, L.part[2].data(), L.part[2].size());
+                break;
+            case K_MATCHES: p = put_int(p, s.matches); break;
+            case K_MISMATCHES: p = put_int(p, s.mismatches); break;
+            case K_GAPS: p = put_int(p, s.gaps); break;
+            case K_SIMILARITY:
+                p = put_int(p, s.similarity_bp / 100);
+                *p++ = '.';
+                if (s.similarity_bp % 100 < 10) *p++ = '0';
+                p = put_int(p, s.similarity_bp % 100);
+                *p++ = '%';
+                break;
+            default: break;
+        }
+    }
+    *p++ = '\n';
+    return (size_t)(p - buf);
+}
+
+bool write_all(int fd, const char* p, size_t n) {
+    while (n) {
+        ssize_t w = write(fd, p, n);
+        if (w < 0) { if (errno == EINTR) continue; return false; }
+        p += w; n -= (size_t)w;
+    }
+    return true;
+}
+
+struct Chunk { uint64_t r0, r1; };
+
+}  // namespace
+
+extern "C" {
+
+void sa_settings_default(sa_settings* st) {
+    memset(st, 0, sizeof(*st));
+    st->max_csv_line = 256;
+    st->max_seq_len = 64;
+    st->gap_penalty = -4;
+    st->read_csv_seq_pos = 0;
+    st->read_csv_cols = 2;
+    snprintf(st->write_csv_header, sizeof(st->write_csv_header), "%s",
+             "sequence1,sequence2,label1,label2,score,alignment,matches,mismatches,gaps,similarity\n");
+    st->write_csv_seq1_pos = 0;
+    st->write_csv_score_pos = 4;
+    st->write_csv_align_pos = 5;
+    st->write_csv_matches_pos = 6;
+    st->write_csv_mismatches_pos = 7;
+    st->write_csv_gaps_pos = 8;
+    st->write_csv_similarity_pos = 9;
+    snprintf(st->write_csv_align_fmt, sizeof(st->write_csv_align_fmt), "%s", "\"('%s', '%s')\"");
+    st->mode_write = 1;
+    st->similarity_analysis = 1;
+    st->batch_size = 32768;
+    st->schedule = SA_SCHEDULE_ADJACENT;
+    st->num_devices = 1;
+    for (int k = 0; k < 8; k++) st->devices[k] = k;
+    st->format_threads = 0;
+    st->pairs_per_submit = 0;
+}
+
+static bool parse_c_string(const char* p, char* out, size_t cap) {
+    while (*p == ' ' || *p == '\t') p++;
+    if (*p != '"') return false;
+    p++;
+    size_t n = 0;
+    while (*p && *p != '"') {
+        char ch = *p++;
+        if (ch == '\\' && *p) {
+            const char e = *p++;
+            ch = e == 'n' ? '\n' : e == 't' ? '\t' : e == 'r' ? '\r' : e;
+        }
+        if (n + 1 >= cap) return false;
+        out[n++] = ch;
+    }
+    out[n] = '\0';
+    return *p == '"';
+}
+
+int sa_settings_load(sa_settings* st, const char* path) {
+    if (!st || !path) return SA_ERR_ARG;
+    FILE* f = fopen(path, "r");
+    if (!f) return SA_ERR_ARG;
+    char line[8192];
+    int rc = SA_OK;
+    while (fgets(line, sizeof(line), f)) {
+        char name[64];
+        int off = 0;
+        if (sscanf(line, " #define %63s %n", name, &off) < 1 || off == 0) continue;
+        const char* v = line + off;
+        const std::string k(name);
+        auto num = [&](long& out) { char* e; out = strtol(v, &e, 0); return e != v; };
+        long x;
+        if (k == "INPUT_FILE") { if (!parse_c_string(v, st->input_file, sizeof(st->input_file))) st->input_file[0] = 0; }
+        else if (k == "OUTPUT_FILE") { if (!parse_c_string(v, st->output_file, sizeof(st->output_file))) st->output_file[0] = 0; }
+        else if (k == "WRITE_CSV_HEADER") { if (!parse_c_string(v, st->write_csv_header, sizeof(st->write_csv_header))) rc = SA_ERR_ARG; }
+        else if (k == "WRITE_CSV_ALIGN_FMT") { if (!parse_c_string(v, st->write_csv_align_fmt, sizeof(st->write_csv_align_fmt))) rc = SA_ERR_ARG; }
+        else if (k == "MAX_CSV_LINE") { if (num(x)) st->max_csv_line = (uint32_t)x; }
+        else if (k == "MAX_SEQ_LEN") { if (num(x)) st->max_seq_len = (uint32_t)x; }
+        else if (k == "GAP_PENALTY") { if (num(x)) st->gap_penalty = (int32_t)x; }
+        else if (k == "READ_CSV_SEQ_POS") { if (num(x)) st->read_csv_seq_pos = (uint32_t)x; }
+        else if (k == "READ_CSV_COLS") { if (num(x)) st->read_csv_cols = (uint32_t)x; }
+        else if (k == "WRITE_CSV_SEQ1_POS") { if (num(x)) st->write_csv_seq1_pos = (uint32_t)x; }
+        else if (k == "WRITE_CSV_SCORE_POS") { if (num(x)) st->write_csv_score_pos = (uint32_t)x; }
+        else if (k == "WRITE_CSV_ALIGN_POS") { if (num(x)) st->write_csv_align_pos = (uint32_t)x; }
+        else if (k == "WRITE_CSV_MATCHES_POS") { if (num(x)) st->write_csv_matches_pos = (uint32_t)x; }
+        else if (k == "WRITE_CSV_MISMATCHES_POS") { if (num(x)) st->write_csv_mismatches_pos = (uint32_t)x; }
+        else if (k == "WRITE_CSV_GAPS_POS") { if (num(x)) st->write_csv_gaps_pos = (uint32_t)x; }
+        else if (k == "WRITE_CSV_SIMILARITY_POS") { if (num(x)) st->write_csv_similarity_pos = (uint32_t)x; }
+        else if (k == "SIMILARITY_ANALYSIS") { if (num(x)) st->similarity_analysis = (int32_t)x; }
+        else if (k == "MODE_WRITE") { if (num(x)) st->mode_write = (int32_t)x; }
+        else if (k == "BATCH_SIZE") { if (num(x)) st->batch_size = (uint32_t)x; }
+        else if (k == "SA_SCHEDULE") { if (num(x)) st->schedule = (int32_t)x; }
+        else if (k == "SA_NUM_DEVICES") { if (num(x)) st->num_devices = (int32_t)x; }
+    }
+    fclose(f);
+    return rc;
+}
+
+int sa_settings_validate(const sa_settings* st, char* message, uint32_t cap) {
+    auto say = [&](const char* m) { if (message && cap) snprintf(message, cap, "%s", m); return SA_ERR_ARG; };
+    if (!st) return SA_ERR_ARG;
+    if (st->gap_penalty >= 0) return say("GAP_PENALTY must be negative");
+    if (st->max_csv_line < 32) return say("MAX_CSV_LINE must be at least 32");
+    if (st->max_seq_len < 2) return say("MAX_SEQ_LEN must be at least 2");
+    if (st->read_csv_cols < 1) return say("READ_CSV_COLS must be at least 1");
+    if (st->read_csv_seq_pos >= st->read_csv_cols) return say("READ_CSV_SEQ_POS must be below READ_CSV_COLS");
+    if (st->batch_size < 2) return say("BATCH_SIZE must be at least 2");
+    const uint32_t want = 2 * st->read_csv_cols + 2 + (st->similarity_analysis ? 4 : 0);
+    uint32_t have = 1;
+    for (const char* p = st->write_csv_header; *p; p++) have += *p == ',';
+    if (have != want) return say("WRITE_CSV_HEADER must have 2*READ_CSV_COLS+2 columns (+4 with SIMILARITY_ANALYSIS)");
+    Layout L;
+    std::string err;
+    if (make_layout(st, L, err) != SA_OK) return say(err.c_str());
+    if (message && cap) message[0] = 0;
+    return SA_OK;
+}
+
+int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
+    if (!st || !rep) return SA_ERR_ARG;
+    memset(rep, 0, sizeof(*rep));
+    std::string err;
+    auto fail = [&](int code) {
+        snprintf(rep->message, sizeof(rep->message), "%s", err.empty() ? sa_strerror(code) : err.c_str());
+        return code;
+    };
+    if (!*st->input_file) { err = "INPUT_FILE is not set"; return fail(SA_ERR_ARG); }
+    if (st->mode_write && !*st->output_file) { err = "OUTPUT_FILE is not set"; return fail(SA_ERR_ARG); }
+    if (st->read_csv_cols < 1 || st->read_csv_seq_pos >= st->read_csv_cols) { err = "READ_CSV_SEQ_POS must be below READ_CSV_COLS"; return fail(SA_ERR_ARG); }
+    if (st->num_devices < 1 || st->num_devices > 8) { err = "1 to 8 devices"; return fail(SA_ERR_ARG); }
+    Layout L;
+    int rc = make_layout(st, L, err);
+    if (rc) return fail(rc);
+
+    // contexts first: like the reference's pool, they are set up outside the timed window (src/main.c:10,30)
+    const int ndev = st->num_devices;
+    std::vector<sa_ctx*> ctx((size_t)ndev, nullptr);
+    auto cleanup = [&]() { for (auto c : ctx) sa_destroy(c); };
+    // the reference's buffers hold sequences shorter than MAX_SEQ_LEN (NUL included, include/thread.h:27-29)
+    const uint32_t max_len = st->max_seq_len ? st->max_seq_len - 1 : 0;
+    if (max_len == 0 || max_len > SA_MAX_PEPTIDE_LEN) { err = "MAX_SEQ_LEN must be between 2 and 65"; return fail(SA_ERR_LENGTH); }
+    for (int d = 0; d < ndev; d++) {
+        rc = sa_init(&ctx[(size_t)d], nullptr, st->gap_penalty, max_len, st->devices[d]);
+        if (rc) { cleanup(); return fail(rc); }
+    }
+
+    int out_fd = -1;
+    if (st->mode_write) {
+        out_fd = open(st->output_file, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        if (out_fd < 0) { err = std::string("cannot open output file: ") + strerror(errno); cleanup(); return fail(SA_ERR_ARG); }
+    }
+
+    const double t0 = now_s();
+    Table tab;
+    rc = load_table(st, tab, err);
+    if (rc) { cleanup(); if (out_fd >= 0) close(out_fd); return fail(rc); }
+    const uint64_t n = tab.rows.size();
+    rep->rows = n;
+
+    // encode + validate (the reference has undefined behaviour here; see include/scoring.h:42, include/csv.h:174,181)
+    std::vector<uint64_t> offs(n);
+    std::vector<uint32_t> lens(n);
+    uint64_t total = 0;
+    for (uint64_t s = 0; s < n; s++) {
+        const Row& r = tab.rows[s];
+        if (r.len == 0 || r.len > max_len) {
+            err = "row " + std::to_string(s + 2) + ": sequence length " + std::to_string(r.len) + " outside 1.." + std::to_string(max_len);
+            cleanup(); if (out_fd >= 0) close(out_fd);
+            return fail(SA_ERR_LENGTH);
+        }
+        offs[s] = total; lens[s] = r.len; total += r.len;
+    }
+    std::vector<uint8_t> codes(total + 1);
+    for (uint64_t s = 0; s < n; s++) {
+        if (sa_encode(tab.rows[s].seq, lens[s], codes.data() + offs[s]) != SA_OK) {
+            err = "row " + std::to_string(s + 2) + ": residue outside " SA_ALPHABET;
+            cleanup(); if (out_fd >= 0) close(out_fd);
+            return fail(SA_ERR_ALPHABET);
+        }
+    }
+    bool io_ok = true;
+    if (out_fd >= 0) io_ok = write_all(out_fd, st->write_csv_header, strlen(st->write_csv_header));
+
+    if (n >= 2) {
+        for (int d = 0; d < ndev; d++) {
+            rc = sa_upload(ctx[(size_t)d], codes.data(), offs.data(), lens.data(), n);
+            if (rc) { cleanup(); if (out_fd >= 0) close(out_fd); return fail(rc); }
+        }
+        const int schedule = st->schedule;
+        const uint64_t rows = sa_schedule_rows(ctx[0], schedule);
+        rep->pairs = sa_pair_count(ctx[0], schedule, 0, rows);
+        rep->cells = sa_cell_count(ctx[0], schedule, 0, rows);
+        const uint32_t stride = sa_record_stride(ctx[0]);
+
+        // chunks of whole schedule rows; chunk k goes to device k % ndev, results are consumed in chunk order
+        uint64_t cap = st->pairs_per_submit ? st->pairs_per_submit : (uint64_t)st->batch_size * 64;
+        if (cap < 1) cap = 1;
+        std::vector<Chunk> chunks;
+        for (uint64_t r0 = 0; r0 < rows;) {
+            uint64_t r1 = r0 + 1;
+            if (schedule == SA_SCHEDULE_ADJACENT) r1 = std::min(rows, r0 + cap);
+            else while (r1 < rows && sa_pair_count(ctx[0], schedule, r0, r1 + 1) <= cap) r1++;
+            chunks.push_back({r0, r1});
+            r0 = r1;
+        }
+        int nthreads = st->format_threads > 0 ? st->format_threads : (int)std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
+        std::vector<std::vector<char>> bufs((size_t)nthreads);
+        std::vector<size_t> used((size_t)nthreads);
+        const size_t row_bound = 4 * (size_t)st->max_seq_len + 2 * 256 + L.part[0].size() + L.part[1].size() + L.part[2].size() + 64;
+
+        size_t next_submit = 0;
+        auto submit_more = [&]() -> int {
+            // keep up to two chunks in flight per device, in chunk order
+            while (next_submit < chunks.size() && next_submit < rep->chunks_done + 2 * (size_t)ndev) {
+                sa_ctx* c = ctx[next_submit % (size_t)ndev];
+                int r = sa_submit(c, schedule, chunks[next_submit].r0, chunks[next_submit].r1);
+                if (r == SA_ERR_BUSY) break;
+                if (r) return r;
+                next_submit++;
+            }
+            return SA_OK;
+        };
+        for (size_t k = 0; k < chunks.size() && rc == SA_OK; k++) {
+            if ((rc = submit_more())) break;
+            sa_ctx* c = ctx[k % (size_t)ndev];
+            const uint8_t* recs = nullptr;
+            uint64_t first = 0, np = 0;
+            if ((rc = sa_next(c, &recs, &first, &np))) break;
+            if (st->mode_write && np) {
+                std::atomic<int> bad(0);
+                auto work = [&](int t) {
+                    const uint64_t lo = np * (uint64_t)t / (uint64_t)nthreads, hi = np * (uint64_t)(t + 1) / (uint64_t)nthreads;
+                    std::vector<char>& b = bufs[(size_t)t];
+                    if (b.size() < (hi - lo) * row_bound + 16) b.resize((hi - lo) * row_bound + 16);
+                    std::vector<char> a1(2 * (size_t)st->max_seq_len + 2), a2(2 * (size_t)st->max_seq_len + 2);
+                    size_t pos = 0;
+                    // pair (i, j) of the first record of this slice
+                    uint64_t i, j;
+                    if (schedule == SA_SCHEDULE_ADJACENT) { i = first + lo; j = i + 1; }
+                    else {
+                        i = chunks[k].r0;
+                        uint64_t idx = first + lo;
+                        while (sa_pair_index(c, schedule, i + 1) <= idx) i++;
+                        j = i + 1 + (idx - sa_pair_index(c, schedule, i));
+                    }
+                    for (uint64_t q = lo; q < hi; q++) {
+                        const Row& r1 = tab.rows[i];
+                        const Row& r2 = tab.rows[j];
+                        sa_alignment_stats s;
+                        if (sa_expand_record(recs + q * stride, stride, r1.seq, r1.len, r2.seq, r2.len, a1.data(), a2.data(), &s) != SA_OK) {
+                            bad.store(1);
+                            break;
+                        }
+                        pos += format_row(b.data() + pos, L, r1, r2, a1.data(), a2.data(), s);
+                        if (schedule == SA_SCHEDULE_ADJACENT) { i++; j++; }
+                        else if (++j == n) { i++; j = i + 1; }
+                    }
+                    used[(size_t)t] = pos;
+                };
+                std::vector<std::thread> th;
+                for (int t = 1; t < nthreads; t++) th.emplace_back(work, t);
+                work(0);
+                for (auto& x : th) x.join();
+                if (bad.load()) { rc = SA_ERR_RECORD; }
+                for (int t = 0; t < nthreads && rc == SA_OK; t++) {
+                    if (!write_all(out_fd, bufs[(size_t)t].data(), used[(size_t)t])) io_ok = false;
+                    rep->bytes_written += used[(size_t)t];
+                }
+            }
+            if (rc == SA_OK) rc = sa_release(c);
+            rep->chunks_done++;
+        }
+    }
+    rep->bytes_written += (out_fd >= 0) ? strlen(st->write_csv_header) : 0;
+    const double t1 = now_s();
+    rep->seconds = t1 - t0;
+    if (out_fd >= 0) close(out_fd);
+    cleanup();
+    if (rc) return fail(rc);
+    if (!io_ok) { err = "write to output file failed"; return fail(SA_ERR_ARG); }
+    return SA_OK;
+}
+
+}  // extern "C"

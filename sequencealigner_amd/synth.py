@@ -40,3 +40,16 @@ def write_csv(path, seqs, labels):
     with open(path, "wb") as f:
         f.write(b"sequence,label\n")
         f.write(b"".join(s + b"," + str(l).encode() + b"\n" for s, l in zip(seqs, labels)))
+
+
+def make_mega(input_csv, output_csv, factor=1920):
+    """The reference's enlarged data set (scripts/create_mega_dataset.py:121-167):
+    header + (body + body with its lines in reverse order) repeated `factor` times."""
+    with open(input_csv, "rb") as f:
+        header = f.readline()
+        body = f.read()
+    doubled = body + b"".join(body.splitlines(True)[::-1])
+    with open(output_csv, "wb") as f:
+        f.write(header)
+        for _ in range(factor):
+            f.write(doubled)
