@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Headline benchmark: all-vs-all Needleman-Wunsch (score + traceback) of the
+synthetic 50 000-peptide set (len 6-50, seed 1; BASELINE.json configs[2]) on N MI355X.
+
+A step is one pass of the hot path over the whole pair space owned by the rank:
+fill + traceback kernels, compact result records left in HBM, inputs resident
+in HBM before the timed region.  With N > 1 the triangular pair space is split
+into N contiguous row ranges of equal cell count, one per rank, with no
+collective on the data path (total work is fixed: strong scaling).
+
+Prints one JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import sequencealigner_amd as sa  # noqa: E402
+from sequencealigner_amd import synth  # noqa: E402
+
+# INT32 VALU peak used for the roofline: 256 CUs x 64 lanes x 2.4 GHz.  Measured on
+# the device with tools/valu_peak.hip: 35-40 T lane-instructions/s for max3 / compare
+# / alignbit / packed ops, 55-64 T for plain add / sub / logic (profiles/r01_valu_issue_rates.txt).
+PEAK_TIOPS = 256 * 64 * 2.4e9 / 1e12
+OPS_PER_CELL = 5          # 3 adds + 2 max of the reference recurrence (include/seqalign.h:55-58)
+
+WORKLOADS = {
+    # name: (n, lo, hi, seed, description)
+    "peptides50k": (50000, 6, 50, 1, "synthetic 50k peptides len 6-50 seed 1, all-vs-all (BASELINE configs[2])"),
+    "peptides20k": (20000, 6, 50, 1, "synthetic 20k peptides len 6-50 seed 1, all-vs-all"),
+    "peptides4k": (4000, 6, 50, 1, "synthetic 4k peptides len 6-50 seed 1, all-vs-all"),
+}
+
+
+def shard_for_rank(al, schedule, rank, world):
+    """Contiguous row range of the schedule owned by `rank`: equal cells per rank."""
+    b = al.shard_rows(schedule, world)
+    return b[rank], b[rank + 1]
+
+
+def reduce_max(x):
+    if dist.is_available() and dist.is_initialized():
+        t = torch.tensor([x], dtype=torch.float64)
+        if dist.get_backend() == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+    return float(x)
+
+
+def reduce_sum(t):
+    if dist.is_available() and dist.is_initialized():
+        if dist.get_backend() == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t.cpu()
+    return t
+
+
+def barrier_sync():
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+
+
+def cpu_baseline(seqs, labels, sample_n):
+    """The CPU restatement (oracle/nw_oracle.c, the reference's multithreaded path
+    re-stated) timed on the host cores of this box on a bounded sample of the same
+    workload: the first `sample_n` sequences, all-vs-all, without writing."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+
+    threads = min(16, os.cpu_count() or 1)
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "sample.csv")
+        synth.write_csv(path, seqs[:sample_n], labels[:sample_n])
+        st = oracle_lib.run_file(path, None, 1, threads=threads)
+    return {
+        "value": round(st.cells / st.seconds / 1e9, 3),
+        "unit": "GCUPS",
+        "pairs_per_s": round(st.pairs / st.seconds, 1),
+        "cores": threads,
+        "kind": "port",
+        "seconds": round(st.seconds, 3),
+        "sample": f"first {sample_n} of the {len(seqs)} sequences, all-vs-all ({st.pairs} pairs, {st.cells} cells), "
+                  f"score + traceback, no CSV write, {threads} threads",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="peptides50k", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-sample", type=int, default=6000, help="sequences in the CPU baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl")
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+
+    n, lo, hi, seed, desc = WORKLOADS[args.workload]
+    seqs, labels = synth.generate(n, lo, hi, seed)
+    al = sa.Aligner(device=local_rank)          # raises if the HIP library or the device is missing
+    al.upload(seqs)
+    r0, r1 = shard_for_rank(al, sa.TRIANGULAR, rank, world)
+    my_pairs = al.pair_count(sa.TRIANGULAR, r0, r1)
+    my_cells = al.cell_count(sa.TRIANGULAR, r0, r1)
+    al.prepare_resident(sa.TRIANGULAR, r0, r1)
+
+    for _ in range(args.warmup):
+        al.run_resident()
+    barrier_sync()
+    t0 = time.perf_counter()
+    kernel_ms = []
+    for _ in range(args.steps):
+        kernel_ms.append(al.run_resident())     # launches on the library's stream and waits for it
+    barrier_sync()
+    elapsed = reduce_max(time.perf_counter() - t0)
+    totals = reduce_sum(torch.tensor([float(my_pairs), float(my_cells)], dtype=torch.float64))
+    total_pairs, total_cells = float(totals[0]), float(totals[1])
+
+    if rank == 0:
+        k_ms = sum(kernel_ms) / max(1, len(kernel_ms))
+        achieved = my_cells * OPS_PER_CELL / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        out = {
+            "metric": "GCUPS, all-vs-all Needleman-Wunsch score+traceback (aligned pairs/s alongside)",
+            "value": round(total_cells * args.steps / elapsed / 1e9, 2),
+            "unit": "GCUPS",
+            "pairs_per_s": round(total_pairs * args.steps / elapsed, 1),
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "int32",
+            "data": "synthetic",
+            "config": {
+                "workload": desc,
+                "sequences": n,
+                "pairs": int(total_pairs),
+                "cells": int(total_cells),
+                "schedule": "triangular, contiguous row ranges of equal cell count per GPU",
+                "results": "64-byte record per pair (score, matches, gaps, traceback) left in HBM",
+            },
+            "roofline": {
+                "bound": "valu_int32",
+                "achieved": round(achieved, 3),
+                "peak": round(PEAK_TIOPS, 2),
+                "unit": "TIOP/s",
+                "frac": round(achieved / PEAK_TIOPS, 4),
+                "traffic": None,
+                "kernel": "sa_peptide_kernel<0>",
+                "kernel_ms": round(k_ms, 3),
+                "cells_per_launch": int(my_cells),
+                "ops_per_cell": OPS_PER_CELL,
+                "note": "INT32 VALU roofline (the path is not HBM- or MFMA-bound): algorithmic ops = 5 per DP cell",
+            },
+        }
+        if world == 1 and args.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(seqs, labels, min(args.cpu_sample, n))
+        print(json.dumps(out), flush=True)
+    al.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

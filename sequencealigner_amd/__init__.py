@@ -7,6 +7,7 @@ symbols resolve), every compute call fails loudly when no device is present.
 from ._lib import (  # noqa: F401
     ADJACENT,
     TRIANGULAR,
+    DEVICE_NONE,
     ALPHABET,
     Aligner,
     SaError,

@@ -11,6 +11,7 @@ import numpy as np
 
 ADJACENT = 0
 TRIANGULAR = 1
+DEVICE_NONE = -1  # host-only context: schedule arithmetic and work lists, no compute
 ALPHABET = "ARNDCQEGHILKMFPSTWYV"
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -108,6 +109,9 @@ SIGNATURES = {
          C.POINTER(AlignmentStats)],
     ),
     "sa_debug_phase_cycles": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]),
+    "sa_debug_work_items": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32), C.c_uint64,
+                                      C.POINTER(C.c_uint64)]),
+    "sa_debug_tile_slots": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint64, C.POINTER(C.c_uint64)]),
     "sa_similarity_bp": (C.c_int, [C.c_int32, C.c_int32]),
     "sa_default_matrix": (None, [C.POINTER(C.c_int32)]),
     # include/sa_host.h
@@ -299,6 +303,23 @@ class Aligner:
         tot = (C.c_uint64 * 8)()
         _check(self._lib.sa_debug_phase_cycles(self._ctx, 1 if enable else 0, tot))
         return list(tot)
+
+    def work_items(self, schedule, r0, r1):
+        """(n, 4) uint32 array {p, tile_begin, count, 0}: the work list for rows [r0, r1)."""
+        n = C.c_uint64()
+        _check(self._lib.sa_debug_work_items(self._ctx, schedule, r0, r1, None, 0, C.byref(n)))
+        arr = np.zeros((max(1, n.value), 4), dtype=np.uint32)
+        _check(self._lib.sa_debug_work_items(self._ctx, schedule, r0, r1, arr.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                             n.value, C.byref(n)))
+        return arr[: n.value]
+
+    def tile_slots(self):
+        """File index held by every tile slot (0xFFFFFFFF = empty), 64 slots per tile."""
+        n = C.c_uint64()
+        _check(self._lib.sa_debug_tile_slots(self._ctx, None, 0, C.byref(n)))
+        arr = np.zeros(max(1, n.value), dtype=np.uint32)
+        _check(self._lib.sa_debug_tile_slots(self._ctx, arr.ctypes.data_as(C.POINTER(C.c_uint32)), n.value, C.byref(n)))
+        return arr[: n.value]
 
     # -- records
     def expand(self, record, i, j):

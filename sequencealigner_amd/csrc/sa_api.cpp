@@ -93,7 +93,7 @@ struct Work {                 // one submitted (or prepared) row range
 }  // namespace
 
 struct sa_ctx {
-    int device = 0;
+    int device = 0;          // -1: host-only context (schedule arithmetic and work lists, no compute)
     int ncu = 0;
     int32_t S[400];
     int32_t gap = -4;
@@ -113,6 +113,7 @@ struct sa_ctx {
     struct Bucket { uint32_t tile_begin, ntiles; std::vector<uint32_t> fi; };
     std::vector<Bucket> buckets;
     std::vector<uint16_t> bucket_of;   // file index -> bucket
+    std::vector<uint32_t> tile_fi_host; // file index of every tile slot (SA_INVALID_FI = empty)
     uint32_t ntiles = 0;
     // device
     DevBuf d_codes, d_len, d_tiles, d_tile_fi, d_tile_len, d_tile_maxlen, d_sprime, d_spill, d_phase;
@@ -305,6 +306,17 @@ int sa_similarity_bp(int32_t matches, int32_t columns) {
 int sa_init(sa_ctx** out, const int32_t* S, int32_t gap, uint32_t max_seq_len, int device) {
     if (!out || max_seq_len == 0) return SA_ERR_ARG;
     if (max_seq_len > SA_MAX_PEPTIDE_LEN) return SA_ERR_LENGTH;
+    if (device == SA_DEVICE_NONE) {
+        sa_ctx* h = new (std::nothrow) sa_ctx();
+        if (!h) return SA_ERR_NOMEM;
+        h->device = SA_DEVICE_NONE;
+        h->ncu = 256;
+        if (S) memcpy(h->S, S, sizeof(h->S)); else sa_default_matrix(h->S);
+        h->gap = gap;
+        h->max_len = max_seq_len;
+        *out = h;
+        return SA_OK;
+    }
     int ndev = 0;
     SA_HIP_TRY(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return SA_ERR_ARG;
@@ -340,6 +352,7 @@ int sa_init(sa_ctx** out, const int32_t* S, int32_t gap, uint32_t max_seq_len, i
 
 void sa_destroy(sa_ctx* c) {
     if (!c) return;
+    if (c->device == SA_DEVICE_NONE) { delete c; return; }
     (void)hipSetDevice(c->device);
     if (c->compute) (void)hipStreamSynchronize(c->compute);
     if (c->copy) (void)hipStreamSynchronize(c->copy);
@@ -368,7 +381,7 @@ int sa_upload(sa_ctx* c, const uint8_t* codes, const uint64_t* offs, const uint3
     if (!c || !codes || !offs || !lens) return SA_ERR_ARG;
     if (nseq == 0 || nseq >= 0xFFFFFFF0ull) return SA_ERR_ARG;
     if (c->inflight) return SA_ERR_STATE;
-    SA_HIP_TRY(hipSetDevice(c->device));
+    if (c->device != SA_DEVICE_NONE) SA_HIP_TRY(hipSetDevice(c->device));
     uint32_t lmin = 0xFFFFFFFFu, lmax = 0;
     for (uint64_t s = 0; s < nseq; s++) {
         if (lens[s] == 0 || lens[s] > c->max_len) return SA_ERR_LENGTH;
@@ -425,6 +438,8 @@ int sa_upload(sa_ctx* c, const uint8_t* codes, const uint64_t* offs, const uint3
                 tiles[(size_t)tile * 4096 + (size_t)i * 64 + lane] = codes[offs[s] + i];
         }
     }
+    c->tile_fi_host = tile_fi;
+    if (c->device == SA_DEVICE_NONE) return SA_OK;
     int rc;
     if ((rc = c->d_codes.reserve(slots.size()))) return rc;
     if ((rc = c->d_len.reserve(nseq + 64))) return rc;
@@ -492,7 +507,7 @@ int sa_shard_rows(const sa_ctx* c, int schedule, uint32_t parts, uint64_t* bound
 
 int sa_submit(sa_ctx* c, int schedule, uint64_t r0, uint64_t r1) {
     if (!c || (schedule != SA_SCHEDULE_ADJACENT && schedule != SA_SCHEDULE_TRIANGULAR)) return SA_ERR_ARG;
-    if (c->nseq < 2) return SA_ERR_STATE;
+    if (c->nseq < 2 || c->device == SA_DEVICE_NONE) return SA_ERR_STATE;
     if (r1 < r0 || r1 > sa_schedule_rows(c, schedule)) return SA_ERR_ARG;
     if (c->inflight == 2) return SA_ERR_BUSY;
     SA_HIP_TRY(hipSetDevice(c->device));
@@ -533,7 +548,7 @@ int sa_release(sa_ctx* c) {
 
 int sa_prepare_resident(sa_ctx* c, int schedule, uint64_t r0, uint64_t r1) {
     if (!c || (schedule != SA_SCHEDULE_ADJACENT && schedule != SA_SCHEDULE_TRIANGULAR)) return SA_ERR_ARG;
-    if (c->nseq < 2) return SA_ERR_STATE;
+    if (c->nseq < 2 || c->device == SA_DEVICE_NONE) return SA_ERR_STATE;
     if (r1 < r0 || r1 > sa_schedule_rows(c, schedule)) return SA_ERR_ARG;
     SA_HIP_TRY(hipSetDevice(c->device));
     c->resident_ready = false;
@@ -569,8 +584,32 @@ int sa_fetch_resident(sa_ctx* c, uint64_t first, uint64_t n, uint8_t* dst) {
     return SA_OK;
 }
 
+int sa_debug_work_items(const sa_ctx* c, int schedule, uint64_t r0, uint64_t r1, uint32_t* items4, uint64_t cap,
+                        uint64_t* count) {
+    if (!c || !count) return SA_ERR_ARG;
+    if (c->nseq < 2) return SA_ERR_STATE;
+    if (r1 < r0 || r1 > sa_schedule_rows(c, schedule)) return SA_ERR_ARG;
+    std::vector<SaItem> items;
+    int rc = build_items(c, schedule, r0, r1, items);
+    if (rc) return rc;
+    *count = items.size();
+    if (items4) {
+        const uint64_t n = std::min<uint64_t>(cap, items.size());
+        memcpy(items4, items.data(), n * sizeof(SaItem));
+    }
+    return SA_OK;
+}
+
+int sa_debug_tile_slots(const sa_ctx* c, uint32_t* file_index, uint64_t cap, uint64_t* count) {
+    if (!c || !count) return SA_ERR_ARG;
+    *count = (uint64_t)c->ntiles * 64;
+    if (file_index) memcpy(file_index, c->tile_fi_host.data(), std::min<uint64_t>(cap, *count) * 4);
+    return SA_OK;
+}
+
 int sa_debug_phase_cycles(sa_ctx* c, int enable, uint64_t totals[8]) {
     if (!c) return SA_ERR_ARG;
+    if (c->device == SA_DEVICE_NONE) return SA_ERR_STATE;
     SA_HIP_TRY(hipSetDevice(c->device));
     if (totals) {
         for (int k = 0; k < 8; k++) totals[k] = 0;

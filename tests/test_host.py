@@ -1,0 +1,227 @@
+"""Host side of the library without a GPU: the shared library loads and exports
+the whole C ABI, records expand correctly, schedules and work lists cover every
+pair exactly once, settings load and validate.  No compute call is made."""
+import ctypes as C
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib
+import sequencealigner_amd as sa
+from sequencealigner_amd import _lib, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ALPHABET = "ARNDCQEGHILKMFPSTWYV"
+
+
+def _declared(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sa_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = sa.load_library()
+    names = _declared("sa_hip.h") + _declared("sa_host.h")
+    assert len(names) >= 25
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in include/ but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no Python binding"
+
+
+def test_compute_fails_loudly_without_device():
+    al = sa.Aligner(device=sa.DEVICE_NONE)
+    al.upload(["ARND", "ARNDC", "WWW"])
+    with pytest.raises(sa.SaError):
+        al.submit(sa.TRIANGULAR, 0, 2)
+    with pytest.raises(sa.SaError):
+        al.prepare_resident(sa.TRIANGULAR, 0, 2)
+
+
+def test_encode_rejects_non_alphabet():
+    lib = sa.load_library()
+    buf = (C.c_uint8 * 8)()
+    assert lib.sa_encode(b"ARND", 4, buf) == 0 and list(buf)[:4] == [0, 1, 2, 3]
+    for bad in (b"ARNB", b"arnd", b"AR-D", b"ARNX"):
+        assert lib.sa_encode(bad, 4, buf) == -2
+
+
+def test_upload_rejects_empty_and_too_long():
+    al = sa.Aligner(device=sa.DEVICE_NONE, max_seq_len=63)
+    with pytest.raises(sa.SaError):
+        al.upload(["ARND", ""])
+    with pytest.raises(sa.SaError):
+        al.upload(["A" * 64, "ARND"])
+    al.upload(["A" * 63, "ARND"])
+
+
+@pytest.mark.parametrize(
+    "m,p,bp",
+    [(57, 100, 5699), (69, 100, 6899), (43, 125, 3439), (51, 125, 4079), (57, 200, 2849), (1, 6, 1666), (6, 6, 10000)],
+)
+def test_similarity_known_answers(m, p, bp):
+    assert sa.similarity_bp(m, p) == bp
+
+
+def test_similarity_equals_oracle_everywhere():
+    lib = sa.load_library()
+    orc = oracle_lib.oracle()
+    for p in range(1, 130):
+        for m in range(0, p + 1):
+            assert lib.sa_similarity_bp(m, p) == orc.sa_oracle_similarity_bp(m, p)
+
+
+def _record_from_alignment(a1, a2, score, stride):
+    """Encode an alignment the way the kernel does: one byte per row of sequence 2."""
+    rec = np.zeros(stride, dtype=np.uint8)
+    matches = sum(1 for x, y in zip(a1, a2) if x == y)
+    gaps = sum(1 for x, y in zip(a1, a2) if x != y and x == "-")
+    rec[0:4] = np.frombuffer(np.int32(score).tobytes(), dtype=np.uint8)
+    rec[4:6] = np.frombuffer(np.uint16(matches).tobytes(), dtype=np.uint8)
+    rec[6:8] = np.frombuffer(np.uint16(gaps).tobytes(), dtype=np.uint8)
+    # walk the columns from the end: LEFT moves (gap in sequence 2) accumulate until a column consumes a row
+    row = sum(1 for y in a2 if y != "-")
+    run = 0
+    for x, y in zip(reversed(a1), reversed(a2)):
+        if y == "-":
+            run += 1
+        else:
+            rec[8 + row - 1] = run * 2 + (1 if x == "-" else 0)
+            run = 0
+            row -= 1
+    return rec
+
+
+def test_expand_record_round_trip_against_oracle():
+    rng = random.Random(3)
+    al = sa.Aligner(device=sa.DEVICE_NONE)
+    seqs = ["".join(rng.choice(ALPHABET) for _ in range(rng.randint(1, 64))) for _ in range(300)]
+    al.upload(seqs)
+    stride = al.stride
+    for k in range(len(seqs) - 1):
+        o1, o2, r = oracle_lib.align(seqs[k], seqs[k + 1])
+        rec = _record_from_alignment(o1.decode(), o2.decode(), r.score, stride)
+        a1, a2, st = al.expand(rec, k, k + 1)
+        assert (a1, a2) == (o1, o2)
+        assert (st.score, st.columns, st.matches, st.mismatches, st.gaps, st.similarity_bp) == (
+            r.score, r.columns, r.matches, r.mismatches, r.gaps, r.similarity_bp)
+
+
+def test_expand_record_rejects_garbage():
+    al = sa.Aligner(device=sa.DEVICE_NONE)
+    al.upload(["ARNDC", "ARN"])
+    rec = np.zeros(al.stride, dtype=np.uint8)
+    rec[8:11] = [200, 0, 0]          # 100 LEFT moves in a 5-residue sequence
+    with pytest.raises(sa.SaError):
+        al.expand(rec, 0, 1)
+
+
+def _pairs_of_items(items, slots, schedule):
+    out = []
+    for p, tile_begin, count, _ in items.tolist():
+        if schedule == sa.ADJACENT:
+            out.extend((p + l, p + l + 1) for l in range(count))
+        else:
+            for tile in range(tile_begin, tile_begin + count):
+                for fi in slots[tile * 64 : tile * 64 + 64].tolist():
+                    if fi != 0xFFFFFFFF and fi > p:
+                        out.append((p, fi))
+    return out
+
+
+@pytest.mark.parametrize("n,lo,hi", [(2, 5, 5), (65, 1, 64), (300, 6, 50), (1042, 6, 46), (3000, 10, 12)])
+def test_work_items_cover_every_pair_once(n, lo, hi):
+    seqs, _ = synth.generate(n, lo, hi, seed=n)
+    al = sa.Aligner(device=sa.DEVICE_NONE)
+    al.upload(seqs)
+    slots = al.tile_slots()
+    assert sorted(x for x in slots.tolist() if x != 0xFFFFFFFF) == list(range(n))
+    for schedule in (sa.ADJACENT, sa.TRIANGULAR):
+        rows = al.rows(schedule)
+        cuts = sorted({0, rows // 3, rows // 2, rows})
+        for r0, r1 in zip(cuts[:-1], cuts[1:]):
+            got = sorted(_pairs_of_items(al.work_items(schedule, r0, r1), slots, schedule))
+            if schedule == sa.ADJACENT:
+                want = [(k, k + 1) for k in range(r0, r1)]
+            else:
+                want = [(i, j) for i in range(r0, r1) for j in range(i + 1, n)]
+            assert got == want
+            assert al.pair_count(schedule, r0, r1) == len(want)
+            cells = sum(len(seqs[i]) * len(seqs[j]) for i, j in want)
+            assert al.cell_count(schedule, r0, r1) == cells
+
+
+def test_pair_index_is_row_major_triangular():
+    seqs, _ = synth.generate(50, 6, 20, seed=5)
+    al = sa.Aligner(device=sa.DEVICE_NONE)
+    al.upload(seqs)
+    idx = 0
+    for i in range(49):
+        assert al.pair_index(sa.TRIANGULAR, i) == idx
+        idx += 49 - i
+    assert al.pair_index(sa.ADJACENT, 17) == 17
+
+
+@pytest.mark.parametrize("parts", [1, 2, 4, 8])
+def test_shard_rows_partition_with_balanced_cells(parts):
+    seqs, _ = synth.generate(4000, 6, 50, seed=1)
+    al = sa.Aligner(device=sa.DEVICE_NONE)
+    al.upload(seqs)
+    for schedule in (sa.ADJACENT, sa.TRIANGULAR):
+        b = al.shard_rows(schedule, parts)
+        assert b[0] == 0 and b[-1] == al.rows(schedule) and all(x <= y for x, y in zip(b, b[1:]))
+        cells = [al.cell_count(schedule, lo, hi) for lo, hi in zip(b, b[1:])]
+        assert sum(cells) == al.cell_count(schedule, 0, al.rows(schedule))
+        assert max(cells) <= 1.02 * sum(cells) / parts + 64 * 64 * 4000
+
+
+def test_synthetic_generator_is_deterministic():
+    a, la = synth.generate(100, 6, 50, seed=1)
+    b, lb = synth.generate(100, 6, 50, seed=1)
+    assert a == b and la == lb
+    assert all(6 <= len(s) <= 50 and set(s) <= set(ALPHABET.encode()) for s in a)
+    assert a[0] != synth.generate(100, 6, 50, seed=2)[0][0]
+
+
+def test_settings_defaults_match_reference_user_h():
+    st = sa.default_settings()
+    assert (st.max_csv_line, st.max_seq_len, st.gap_penalty, st.batch_size) == (256, 64, -4, 32768)
+    assert (st.read_csv_seq_pos, st.read_csv_cols, st.mode_write, st.similarity_analysis) == (0, 2, 1, 1)
+    assert st.write_csv_header == b"sequence1,sequence2,label1,label2,score,alignment,matches,mismatches,gaps,similarity\n"
+    assert st.write_csv_align_fmt == b"\"('%s', '%s')\""
+    assert sa.validate_settings(st) == (0, "")
+
+
+def test_settings_load_from_user_h_style_file(tmp_path):
+    f = tmp_path / "user.h"
+    f.write_text(
+        '#ifndef USER_H\n#define USER_H\n// comment\n#define MAX_CSV_LINE 512\n#define MAX_SEQ_LEN 48\n'
+        '#define GAP_PENALTY -7\n#define READ_CSV_HEADER "sequence,label\\n"\n#define READ_CSV_SEQ_POS 0\n'
+        '#define READ_CSV_COLS 2\n#define WRITE_CSV_HEADER "a,b,c,d,e,f\\n"\n#define WRITE_CSV_SEQ1_POS 2\n'
+        '#define WRITE_CSV_SCORE_POS 0\n#define WRITE_CSV_ALIGN_POS 1\n#define WRITE_CSV_ALIGN_FMT "%s|%s"\n'
+        '#define INPUT_FILE "/data/in.csv"\n#define OUTPUT_FILE "/data/out.csv"\n#define MODE_MULTITHREAD 1\n'
+        '#define SIMILARITY_ANALYSIS 0\n#define MODE_WRITE 1\n#define BATCH_SIZE 4096\n#endif\n')
+    st = sa.load_settings(str(f))
+    assert (st.max_csv_line, st.max_seq_len, st.gap_penalty, st.batch_size) == (512, 48, -7, 4096)
+    assert st.input_file == b"/data/in.csv" and st.output_file == b"/data/out.csv"
+    assert st.write_csv_header == b"a,b,c,d,e,f\n" and st.write_csv_align_fmt == b"%s|%s"
+    assert (st.write_csv_seq1_pos, st.write_csv_score_pos, st.write_csv_align_pos, st.similarity_analysis) == (2, 0, 1, 0)
+    assert sa.validate_settings(st)[0] == 0
+
+
+def test_settings_validation_rules():
+    st = sa.default_settings()
+    st.gap_penalty = 0
+    assert sa.validate_settings(st)[0] != 0
+    st = sa.default_settings()
+    st.write_csv_score_pos = 0          # collides with sequence 1
+    assert sa.validate_settings(st)[0] != 0
+    st = sa.default_settings()
+    st.write_csv_align_fmt = b"only one %s"
+    assert sa.validate_settings(st)[0] != 0
+    st = sa.default_settings()
+    st.write_csv_header = b"too,few,columns\n"
+    assert sa.validate_settings(st)[0] != 0
