@@ -102,7 +102,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="peptides50k", choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-sample", type=int, default=6000, help="sequences in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=20000, help="sequences in the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -100,7 +100,7 @@ struct sa_ctx {
     uint32_t max_len = 64;
     hipStream_t compute = nullptr, copy = nullptr;
     // tuning
-    uint32_t lds_dir_bytes = 15 * 1024;
+    uint32_t lds_dir_bytes = 8 * 1024;   // with the fixed LDS part this admits 8 workgroups per CU
     uint32_t tiles_per_item = 8;
     uint32_t wg_per_cu = 8;
     // sequences (host mirror)

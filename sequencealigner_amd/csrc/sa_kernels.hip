@@ -260,6 +260,8 @@ __device__ __forceinline__ void traceback(const int lane, const int maxlen, cons
             process(ch - 2, c2);
         }
     }
+    // body bytes past the last chunk are zero, so that equal inputs give equal records
+    for (int z = ((maxlen - 1) >> 2) + 1; z < SA_LDS_STAGE_DWORDS - 2; z++) stage_rec[2 + z] = 0;
     matches_out = matches;
     gaps_out = gaps;
 }
