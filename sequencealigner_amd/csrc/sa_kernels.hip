@@ -266,8 +266,8 @@ __device__ __forceinline__ void traceback(const int lane, const int maxlen, cons
     gaps_out = gaps;
 }
 
-template <int MODE>
-__global__ void __launch_bounds__(64, 2) sa_peptide_kernel(const SaPepParams P) {
+template <int MODE, int WAVES_PER_SIMD>
+__global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_kernel(const SaPepParams P) {
     extern __shared__ __align__(16) uint8_t smem[];
     int32_t* const prof = reinterpret_cast<int32_t*>(smem);
     uint64_t* const emask = reinterpret_cast<uint64_t*>(smem + SA_LDS_PROF_BYTES);
@@ -480,7 +480,7 @@ __global__ void __launch_bounds__(64, 2) sa_peptide_kernel(const SaPepParams P) 
 extern "C" void sa_launch_peptide(int mode, const SaPepParams* p, unsigned grid, unsigned lds_bytes,
                                   hipStream_t stream) {
     if (mode == SA_MODE_TRI)
-        hipLaunchKernelGGL(sa_peptide_kernel<SA_MODE_TRI>, dim3(grid), dim3(64), lds_bytes, stream, *p);
+        hipLaunchKernelGGL((sa_peptide_kernel<SA_MODE_TRI, 3>), dim3(grid), dim3(64), lds_bytes, stream, *p);
     else
-        hipLaunchKernelGGL(sa_peptide_kernel<SA_MODE_ADJ>, dim3(grid), dim3(64), lds_bytes, stream, *p);
+        hipLaunchKernelGGL((sa_peptide_kernel<SA_MODE_ADJ, 2>), dim3(grid), dim3(64), lds_bytes, stream, *p);
 }

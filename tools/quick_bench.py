@@ -11,7 +11,7 @@ rows = al.rows(sa.TRIANGULAR)
 pairs = al.pair_count(sa.TRIANGULAR, 0, rows); cells = al.cell_count(sa.TRIANGULAR, 0, rows)
 print('pairs', pairs, 'cells', cells, 'stride', al.stride, 'out GB', pairs*al.stride/1e9, flush=True)
 for lds in [int(x) for x in (sys.argv[2].split(',') if len(sys.argv) > 2 else ['15'])]:
-    al.set_tuning(lds_dir_bytes=lds*1024)
+    al.set_tuning(lds_dir_bytes=lds*1024, wg_per_cu=int(sys.argv[3]) if len(sys.argv) > 3 else 0)
     t = time.time(); al.prepare_resident(sa.TRIANGULAR, 0, rows); print('prepare', time.time()-t, flush=True)
     for it in range(3):
         ms = al.run_resident()
