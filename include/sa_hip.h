@@ -123,13 +123,15 @@ int sa_set_tuning(sa_ctx* ctx, uint32_t lds_dir_bytes, uint32_t tiles_per_item, 
  * 5 record store), summed over workgroups; totals (may be NULL) receives the sums of
  * the previous launch.  Timed launches run a few percent slower. */
 int sa_debug_phase_cycles(sa_ctx* ctx, int enable, uint64_t totals[8]);
-/* diagnostic: the work list the kernels would pull for rows [row_begin,row_end), four
- * uint32 per item {p, tile_begin, count, 0} (TRIANGULAR: first sequence p against
- * tiles [tile_begin, tile_begin+count); ADJACENT: pairs p .. p+count-1), and the file
- * index held by every tile slot (0xFFFFFFFF = empty; 64 slots per tile). */
-int sa_debug_work_items(const sa_ctx* ctx, int schedule, uint64_t row_begin, uint64_t row_end,
-                        uint32_t* items4, uint64_t cap, uint64_t* count);
-int sa_debug_tile_slots(const sa_ctx* ctx, uint32_t* file_index, uint64_t cap, uint64_t* count);
+/* diagnostic: the work list the kernels would pull for rows [row_begin,row_end), eight
+ * uint32 per item {p, v0, count, b0, c0, 0, 0, 0}.  TRIANGULAR: first sequence p
+ * against entries [v0, v0 + 64*count) of its valid list, i.e. of the sequences with a
+ * larger file index taken in bucket order (sa_debug_bucket_order); ADJACENT: pairs
+ * p .. p+count-1. */
+int sa_debug_work_items(sa_ctx* ctx, int schedule, uint64_t row_begin, uint64_t row_end,
+                        uint32_t* items8, uint64_t cap, uint64_t* count);
+/* diagnostic: file index of every sequence in bucket order (length bucket, then file index) */
+int sa_debug_bucket_order(sa_ctx* ctx, uint32_t* file_index, uint64_t cap, uint64_t* count);
 
 /* ---- records -> what the reference's Alignment holds (host only, no GPU).
  * seq1/seq2 are the ASCII sequences of the pair; a1/a2 receive the aligned

@@ -111,7 +111,7 @@ SIGNATURES = {
     "sa_debug_phase_cycles": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]),
     "sa_debug_work_items": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32), C.c_uint64,
                                       C.POINTER(C.c_uint64)]),
-    "sa_debug_tile_slots": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint64, C.POINTER(C.c_uint64)]),
+    "sa_debug_bucket_order": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint64, C.POINTER(C.c_uint64)]),
     "sa_similarity_bp": (C.c_int, [C.c_int32, C.c_int32]),
     "sa_default_matrix": (None, [C.POINTER(C.c_int32)]),
     # include/sa_host.h
@@ -305,20 +305,21 @@ class Aligner:
         return list(tot)
 
     def work_items(self, schedule, r0, r1):
-        """(n, 4) uint32 array {p, tile_begin, count, 0}: the work list for rows [r0, r1)."""
+        """(n, 8) uint32 array {p, v0, count, b0, c0, 0, 0, 0}: the work list for rows [r0, r1)."""
         n = C.c_uint64()
         _check(self._lib.sa_debug_work_items(self._ctx, schedule, r0, r1, None, 0, C.byref(n)))
-        arr = np.zeros((max(1, n.value), 4), dtype=np.uint32)
+        arr = np.zeros((max(1, n.value), 8), dtype=np.uint32)
         _check(self._lib.sa_debug_work_items(self._ctx, schedule, r0, r1, arr.ctypes.data_as(C.POINTER(C.c_uint32)),
                                              n.value, C.byref(n)))
         return arr[: n.value]
 
-    def tile_slots(self):
-        """File index held by every tile slot (0xFFFFFFFF = empty), 64 slots per tile."""
+    def bucket_order(self):
+        """File index of every sequence in bucket order (length bucket, then file index)."""
         n = C.c_uint64()
-        _check(self._lib.sa_debug_tile_slots(self._ctx, None, 0, C.byref(n)))
+        _check(self._lib.sa_debug_bucket_order(self._ctx, None, 0, C.byref(n)))
         arr = np.zeros(max(1, n.value), dtype=np.uint32)
-        _check(self._lib.sa_debug_tile_slots(self._ctx, arr.ctypes.data_as(C.POINTER(C.c_uint32)), n.value, C.byref(n)))
+        _check(self._lib.sa_debug_bucket_order(self._ctx, arr.ctypes.data_as(C.POINTER(C.c_uint32)), n.value,
+                                               C.byref(n)))
         return arr[: n.value]
 
     # -- records

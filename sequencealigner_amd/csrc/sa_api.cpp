@@ -107,18 +107,20 @@ struct sa_ctx {
     uint32_t wg_per_cu = 12;
     // sequences (host mirror)
     uint64_t nseq = 0;
-    std::vector<uint8_t> len;          // file order
+    std::vector<uint16_t> len;         // file order
     std::vector<uint64_t> len_suffix;  // len_suffix[i] = sum of len[i..]
-    uint32_t max_seq = 0;              // longest uploaded sequence
+    std::vector<uint8_t> codes_host;   // concatenated residue codes, file order
+    std::vector<uint64_t> offs_host;
+    uint32_t min_seq = 0, max_seq = 0; // shortest / longest uploaded sequence
     uint32_t stride = 80;
-    // buckets
-    struct Bucket { uint32_t tile_begin, ntiles; std::vector<uint32_t> fi; };
-    std::vector<Bucket> buckets;
-    std::vector<uint16_t> bucket_of;   // file index -> bucket
-    std::vector<uint32_t> tile_fi_host; // file index of every tile slot (SA_INVALID_FI = empty)
-    uint32_t ntiles = 0;
+    // bucket order (built on first TRIANGULAR use)
+    bool tri_ready = false;
+    uint32_t nb = 0, npad = 0;
+    std::vector<uint32_t> bucket_base;   // [nb+1]
+    std::vector<uint32_t> fi_sorted;     // [nseq] file index of each bucket-order slot
+    std::vector<uint32_t> cursor;        // [nseq][nb] entries of bucket b with file index <= p
     // device
-    DevBuf d_codes, d_len, d_tiles, d_tile_fi, d_tile_len, d_tile_maxlen, d_sprime, d_spill, d_phase;
+    DevBuf d_codes, d_len, d_codes_t, d_fi_sorted, d_len_sorted, d_bucket_base, d_cursor, d_sprime, d_spill, d_phase;
     bool phase_timers = false;
     uint32_t spill_grid = 0;
     Work slots[2];
@@ -131,40 +133,92 @@ namespace {
 
 uint64_t tri_row_start(uint64_t n, uint64_t i) { return i * (2 * n - i - 1) / 2; }
 
-int build_items(const sa_ctx* c, int schedule, uint64_t r0, uint64_t r1, std::vector<SaItem>& items) {
+// Bucket order of the sequences and the cursor table (see sa_device.h); TRIANGULAR only.
+int ensure_triangular(sa_ctx* c) {
+    if (c->tri_ready) return SA_OK;
+    const uint64_t n = c->nseq;
+    // length buckets: exact lengths when every length has plenty of sequences, wider otherwise
+    const uint32_t range = c->max_seq - c->min_seq + 1;
+    uint32_t width = (uint32_t)((256ull * range + n - 1) / n);
+    width = std::max(1u, std::min(width, 64u));
+    const uint32_t nb = (range + width - 1) / width;
+    if ((uint64_t)nb * n > (1ull << 28)) return SA_ERR_NOMEM;   // cursor table of more than 1 GiB
+    c->nb = nb;
+    std::vector<uint32_t> count(nb + 1, 0);
+    std::vector<uint16_t> bucket_of(n);
+    for (uint64_t s = 0; s < n; s++) {
+        bucket_of[s] = (uint16_t)((c->len[s] - c->min_seq) / width);
+        count[bucket_of[s] + 1]++;
+    }
+    c->bucket_base.assign(nb + 1, 0);
+    for (uint32_t b = 0; b < nb; b++) c->bucket_base[b + 1] = c->bucket_base[b] + count[b + 1];
+    c->npad = (uint32_t)((n + 63) / 64 * 64 + 64);
+    c->fi_sorted.assign(n, 0);
+    std::vector<uint16_t> len_sorted(c->npad, 0);
+    std::vector<uint8_t> codes_t((size_t)SA_LP * c->npad, SA_PAD_CODE);
+    std::vector<uint32_t> fill(c->bucket_base.begin(), c->bucket_base.end() - 1);
+    c->cursor.assign((size_t)n * nb, 0);
+    std::vector<uint32_t> running(nb, 0);
+    for (uint64_t s = 0; s < n; s++) {          // ascending file index: every bucket ends up ordered by it
+        const uint32_t b = bucket_of[s];
+        const uint32_t slot = fill[b]++;
+        c->fi_sorted[slot] = (uint32_t)s;
+        len_sorted[slot] = c->len[s];
+        const uint8_t* src = c->codes_host.data() + c->offs_host[s];
+        for (uint32_t i = 0; i < c->len[s]; i++) codes_t[(size_t)i * c->npad + slot] = src[i];
+        running[b]++;
+        memcpy(&c->cursor[(size_t)s * nb], running.data(), nb * sizeof(uint32_t));
+    }
+    if (c->device != SA_DEVICE_NONE) {
+        int rc;
+        std::vector<uint32_t> fi_pad(c->npad, SA_INVALID_FI);
+        memcpy(fi_pad.data(), c->fi_sorted.data(), n * 4);
+        if ((rc = c->d_codes_t.reserve(codes_t.size()))) return rc;
+        if ((rc = c->d_fi_sorted.reserve(fi_pad.size() * 4))) return rc;
+        if ((rc = c->d_len_sorted.reserve(len_sorted.size() * 2))) return rc;
+        if ((rc = c->d_bucket_base.reserve(c->bucket_base.size() * 4))) return rc;
+        if ((rc = c->d_cursor.reserve(c->cursor.size() * 4))) return rc;
+        SA_HIP_TRY(hipMemcpy(c->d_codes_t.p, codes_t.data(), codes_t.size(), hipMemcpyHostToDevice));
+        SA_HIP_TRY(hipMemcpy(c->d_fi_sorted.p, fi_pad.data(), fi_pad.size() * 4, hipMemcpyHostToDevice));
+        SA_HIP_TRY(hipMemcpy(c->d_len_sorted.p, len_sorted.data(), len_sorted.size() * 2, hipMemcpyHostToDevice));
+        SA_HIP_TRY(hipMemcpy(c->d_bucket_base.p, c->bucket_base.data(), c->bucket_base.size() * 4, hipMemcpyHostToDevice));
+        SA_HIP_TRY(hipMemcpy(c->d_cursor.p, c->cursor.data(), c->cursor.size() * 4, hipMemcpyHostToDevice));
+    }
+    c->tri_ready = true;
+    return SA_OK;
+}
+
+int build_items(sa_ctx* c, int schedule, uint64_t r0, uint64_t r1, std::vector<SaItem>& items) {
     items.clear();
+    SaItem it;
+    memset(&it, 0, sizeof(it));
     if (schedule == SA_SCHEDULE_ADJACENT) {
         for (uint64_t k = r0; k < r1; k += 64) {
-            SaItem it;
-            it.p = (uint32_t)k; it.tile_begin = 0;
-            it.count = (uint32_t)std::min<uint64_t>(64, r1 - k); it.reserved = 0;
+            it.p = (uint32_t)k;
+            it.count = (uint32_t)std::min<uint64_t>(64, r1 - k);
             items.push_back(it);
         }
         return SA_OK;
     }
-    const size_t nb = c->buckets.size();
-    // cursor[b] = number of sequences of bucket b with file index <= p
-    std::vector<uint32_t> cursor(nb);
-    for (size_t b = 0; b < nb; b++) {
-        const auto& fi = c->buckets[b].fi;
-        cursor[b] = (uint32_t)(std::upper_bound(fi.begin(), fi.end(), (uint32_t)r0) - fi.begin());
-    }
-    const uint32_t per = c->tiles_per_item;
+    int rc = ensure_triangular(c);
+    if (rc) return rc;
+    const uint32_t nb = c->nb, per = std::max(1u, c->tiles_per_item);
     for (uint64_t p = r0; p < r1; p++) {
-        if (p > r0) cursor[c->bucket_of[p]]++;
-        for (size_t b = 0; b < nb; b++) {
-            const auto& B = c->buckets[b];
-            const uint32_t pos = cursor[b];
-            if (pos >= B.fi.size()) continue;
-            uint32_t t = B.tile_begin + pos / 64;
-            const uint32_t tend = B.tile_begin + B.ntiles;
-            while (t < tend) {
-                SaItem it;
-                it.p = (uint32_t)p; it.tile_begin = t;
-                it.count = std::min(per, tend - t); it.reserved = 0;
-                items.push_back(it);
-                t += it.count;
+        const uint32_t nvalid = (uint32_t)(c->nseq - 1 - p);
+        const uint32_t* cur = &c->cursor[(size_t)p * nb];
+        uint32_t b = 0, cum = 0;
+        for (uint32_t v0 = 0; v0 < nvalid; v0 += per * 64) {
+            // bucket that holds entry v0 of p's valid list
+            for (;;) {
+                const uint32_t cnt = c->bucket_base[b + 1] - c->bucket_base[b] - cur[b];
+                if (cum + cnt > v0) break;
+                cum += cnt;
+                b++;
             }
+            it.p = (uint32_t)p; it.v0 = v0;
+            it.count = std::min(per, (nvalid - v0 + 63) / 64);
+            it.b0 = b; it.c0 = cum;
+            items.push_back(it);
         }
     }
     return SA_OK;
@@ -194,11 +248,14 @@ int launch_work(sa_ctx* c, Work& w, bool timed) {
     SaPepParams P;
     memset(&P, 0, sizeof(P));
     P.codes_fo = (const uint8_t*)c->d_codes.p;
-    P.len_fo = (const uint8_t*)c->d_len.p;
-    P.tiles = (const uint8_t*)c->d_tiles.p;
-    P.tile_fi = (const uint32_t*)c->d_tile_fi.p;
-    P.tile_len = (const uint8_t*)c->d_tile_len.p;
-    P.tile_maxlen = (const uint8_t*)c->d_tile_maxlen.p;
+    P.len_fo = (const uint16_t*)c->d_len.p;
+    P.codes_t = (const uint8_t*)c->d_codes_t.p;
+    P.fi_sorted = (const uint32_t*)c->d_fi_sorted.p;
+    P.len_sorted = (const uint16_t*)c->d_len_sorted.p;
+    P.bucket_base = (const uint32_t*)c->d_bucket_base.p;
+    P.cursor = (const uint32_t*)c->d_cursor.p;
+    P.nb = c->nb;
+    P.npad = c->npad;
     P.sprime = (const int32_t*)c->d_sprime.p;
     P.items = (const SaItem*)w.items.p;
     P.nitems = w.nitems;
@@ -359,8 +416,9 @@ void sa_destroy(sa_ctx* c) {
     if (c->compute) (void)hipStreamSynchronize(c->compute);
     if (c->copy) (void)hipStreamSynchronize(c->copy);
     free_work(c->slots[0]); free_work(c->slots[1]); free_work(c->resident);
-    c->d_codes.release(); c->d_len.release(); c->d_tiles.release(); c->d_tile_fi.release();
-    c->d_tile_len.release(); c->d_tile_maxlen.release(); c->d_sprime.release(); c->d_spill.release();
+    c->d_codes.release(); c->d_len.release(); c->d_codes_t.release(); c->d_fi_sorted.release();
+    c->d_len_sorted.release(); c->d_bucket_base.release(); c->d_cursor.release(); c->d_sprime.release();
+    c->d_spill.release();
     c->d_phase.release();
     if (c->compute) (void)hipStreamDestroy(c->compute);
     if (c->copy) (void)hipStreamDestroy(c->copy);
@@ -392,70 +450,32 @@ int sa_upload(sa_ctx* c, const uint8_t* codes, const uint64_t* offs, const uint3
             if (codes[offs[s] + i] >= 20) return SA_ERR_ALPHABET;
     }
     c->nseq = nseq;
+    c->min_seq = lmin;
     c->max_seq = lmax;
     c->stride = (SA_REC_HEADER_BYTES + lmax + 15u) & ~15u;
     c->resident_ready = false;
+    c->tri_ready = false;
 
-    // file-order slots, left-aligned, padded with SA_PAD_CODE (plus two spare slots)
+    // file-order slots padded with SA_PAD_CODE (plus two spare slots)
     std::vector<uint8_t> slots((size_t)(nseq + 2) * SA_LP, SA_PAD_CODE);
     c->len.assign(nseq, 0);
+    c->offs_host.assign(offs, offs + nseq);
+    uint64_t total = 0;
+    for (uint64_t s = 0; s < nseq; s++) total = std::max(total, offs[s] + lens[s]);
+    c->codes_host.assign(codes, codes + total);
     for (uint64_t s = 0; s < nseq; s++) {
-        c->len[s] = (uint8_t)lens[s];
+        c->len[s] = (uint16_t)lens[s];
         memcpy(&slots[(size_t)s * SA_LP], codes + offs[s], lens[s]);
     }
     c->len_suffix.assign(nseq + 1, 0);
     for (uint64_t s = nseq; s-- > 0;) c->len_suffix[s] = c->len_suffix[s + 1] + c->len[s];
-
-    // length buckets: exact lengths when every length has plenty of sequences, wider otherwise
-    const uint32_t range = lmax - lmin + 1;
-    uint32_t width = (uint32_t)((256ull * range + nseq - 1) / nseq);
-    width = std::max(1u, std::min(width, 64u));
-    const uint32_t nb = (range + width - 1) / width;
-    c->buckets.assign(nb, sa_ctx::Bucket());
-    c->bucket_of.assign(nseq, 0);
-    for (uint64_t s = 0; s < nseq; s++) {
-        const uint32_t b = (lens[s] - lmin) / width;
-        c->bucket_of[s] = (uint16_t)b;
-        c->buckets[b].fi.push_back((uint32_t)s);   // ascending file index by construction
-    }
-    uint32_t t = 0;
-    for (auto& B : c->buckets) {
-        B.tile_begin = t;
-        B.ntiles = (uint32_t)((B.fi.size() + 63) / 64);
-        t += B.ntiles;
-    }
-    c->ntiles = t;
-    std::vector<uint8_t> tiles((size_t)t * 4096 + 4096, SA_PAD_CODE);
-    std::vector<uint32_t> tile_fi((size_t)t * 64 + 64, SA_INVALID_FI);
-    std::vector<uint8_t> tile_len((size_t)t * 64 + 64, 0);
-    std::vector<uint8_t> tile_maxlen((size_t)t + 64, 0);
-    for (const auto& B : c->buckets) {
-        for (size_t k = 0; k < B.fi.size(); k++) {
-            const uint32_t s = B.fi[k];
-            const uint32_t tile = B.tile_begin + (uint32_t)(k / 64), lane = (uint32_t)(k % 64);
-            tile_fi[(size_t)tile * 64 + lane] = s;
-            tile_len[(size_t)tile * 64 + lane] = (uint8_t)lens[s];
-            tile_maxlen[tile] = std::max<uint8_t>(tile_maxlen[tile], (uint8_t)lens[s]);
-            for (uint32_t i = 0; i < lens[s]; i++)
-                tiles[(size_t)tile * 4096 + (size_t)i * 64 + lane] = codes[offs[s] + i];
-        }
-    }
-    c->tile_fi_host = tile_fi;
     if (c->device == SA_DEVICE_NONE) return SA_OK;
     int rc;
     if ((rc = c->d_codes.reserve(slots.size()))) return rc;
-    if ((rc = c->d_len.reserve(nseq + 64))) return rc;
-    if ((rc = c->d_tiles.reserve(tiles.size()))) return rc;
-    if ((rc = c->d_tile_fi.reserve(tile_fi.size() * 4))) return rc;
-    if ((rc = c->d_tile_len.reserve(tile_len.size()))) return rc;
-    if ((rc = c->d_tile_maxlen.reserve(tile_maxlen.size()))) return rc;
+    if ((rc = c->d_len.reserve((nseq + 64) * 2))) return rc;
     SA_HIP_TRY(hipMemcpy(c->d_codes.p, slots.data(), slots.size(), hipMemcpyHostToDevice));
-    SA_HIP_TRY(hipMemset(c->d_len.p, 0, nseq + 64));
-    SA_HIP_TRY(hipMemcpy(c->d_len.p, c->len.data(), nseq, hipMemcpyHostToDevice));
-    SA_HIP_TRY(hipMemcpy(c->d_tiles.p, tiles.data(), tiles.size(), hipMemcpyHostToDevice));
-    SA_HIP_TRY(hipMemcpy(c->d_tile_fi.p, tile_fi.data(), tile_fi.size() * 4, hipMemcpyHostToDevice));
-    SA_HIP_TRY(hipMemcpy(c->d_tile_len.p, tile_len.data(), tile_len.size(), hipMemcpyHostToDevice));
-    SA_HIP_TRY(hipMemcpy(c->d_tile_maxlen.p, tile_maxlen.data(), tile_maxlen.size(), hipMemcpyHostToDevice));
+    SA_HIP_TRY(hipMemset(c->d_len.p, 0, (nseq + 64) * 2));
+    SA_HIP_TRY(hipMemcpy(c->d_len.p, c->len.data(), nseq * 2, hipMemcpyHostToDevice));
     return SA_OK;
 }
 
@@ -586,7 +606,7 @@ int sa_fetch_resident(sa_ctx* c, uint64_t first, uint64_t n, uint8_t* dst) {
     return SA_OK;
 }
 
-int sa_debug_work_items(const sa_ctx* c, int schedule, uint64_t r0, uint64_t r1, uint32_t* items4, uint64_t cap,
+int sa_debug_work_items(sa_ctx* c, int schedule, uint64_t r0, uint64_t r1, uint32_t* items8, uint64_t cap,
                         uint64_t* count) {
     if (!c || !count) return SA_ERR_ARG;
     if (c->nseq < 2) return SA_ERR_STATE;
@@ -595,17 +615,20 @@ int sa_debug_work_items(const sa_ctx* c, int schedule, uint64_t r0, uint64_t r1,
     int rc = build_items(c, schedule, r0, r1, items);
     if (rc) return rc;
     *count = items.size();
-    if (items4) {
+    if (items8) {
         const uint64_t n = std::min<uint64_t>(cap, items.size());
-        memcpy(items4, items.data(), n * sizeof(SaItem));
+        memcpy(items8, items.data(), n * sizeof(SaItem));
     }
     return SA_OK;
 }
 
-int sa_debug_tile_slots(const sa_ctx* c, uint32_t* file_index, uint64_t cap, uint64_t* count) {
+int sa_debug_bucket_order(sa_ctx* c, uint32_t* file_index, uint64_t cap, uint64_t* count) {
     if (!c || !count) return SA_ERR_ARG;
-    *count = (uint64_t)c->ntiles * 64;
-    if (file_index) memcpy(file_index, c->tile_fi_host.data(), std::min<uint64_t>(cap, *count) * 4);
+    if (c->nseq < 2) return SA_ERR_STATE;
+    int rc = ensure_triangular(c);
+    if (rc) return rc;
+    *count = c->nseq;
+    if (file_index) memcpy(file_index, c->fi_sorted.data(), std::min<uint64_t>(cap, *count) * 4);
     return SA_OK;
 }
 

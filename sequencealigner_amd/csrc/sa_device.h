@@ -6,12 +6,14 @@
  *   file order, one 64-byte slot per sequence (slot[0 .. len) = residue codes,
  *     the rest = SA_PAD_CODE).  A slot is the column operand of the DP:
  *     register column c holds slot[c].
- *   length-bucketed tiles, 64 sequences per tile, stored position-major
- *     (tile[pos][lane], LEFT-aligned, 4 KiB per tile): lane l of a wave reads
- *     row residue i of "its" sequence with one coalesced 64-byte load.
- *     Within a bucket the sequences are ordered by file index, so for a given
- *     first sequence p the partners with a larger file index form a suffix of
- *     each bucket.
+ *   bucket order, position-major: the sequences are sorted by (length bucket,
+ *     file index) and stored as codes_t[pos][sorted index], so the 64 lanes of a
+ *     wave, which hold consecutive sorted indices, read row residue i of "their"
+ *     sequences with one coalesced 64-byte load.  Inside a bucket the order is
+ *     by file index, so for a given first sequence p the partners with a larger
+ *     file index form a suffix of each bucket; cursor[p][b] is where that suffix
+ *     starts.  The partners of p, bucket after bucket, are its "valid list";
+ *     a wave takes 64 consecutive entries of it, whatever buckets they come from.
  */
 #ifndef SA_DEVICE_H
 #define SA_DEVICE_H
@@ -34,14 +36,18 @@
 #define SA_LDS_STAGE_BYTES (64 * SA_LDS_STAGE_DWORDS * 4)
 #define SA_LDS_FIXED_BYTES (SA_LDS_PROF_BYTES + SA_LDS_EMASK_BYTES + SA_LDS_STAGE_BYTES)
 
-/* One unit of work pulled from the device-side queue.
- * TRIANGULAR: first sequence p (file index) against tiles [tile_begin, tile_begin+count).
+/* One unit of work pulled from the device-side queue (32 bytes).
+ * TRIANGULAR: first sequence p (file index) against entries
+ *             [v0, v0 + 64*count) of its valid list; b0 is the bucket that holds
+ *             entry v0 and c0 the number of valid entries in the buckets before b0.
  * ADJACENT:   pairs (p+l, p+l+1) for l in [0, count), count <= 64. */
 typedef struct {
     uint32_t p;
-    uint32_t tile_begin;
+    uint32_t v0;
     uint32_t count;
-    uint32_t reserved;
+    uint32_t b0;
+    uint32_t c0;
+    uint32_t reserved[3];
 } SaItem;
 
 /* Result record, `stride` bytes per pair (multiple of 16):
@@ -58,11 +64,14 @@ typedef struct {
 
 typedef struct {
     const uint8_t* codes_fo;     /* [N][64] residue codes padded with SA_PAD_CODE, file order */
-    const uint8_t* len_fo;       /* [N] */
-    const uint8_t* tiles;        /* [T][64 pos][64 lanes] left-aligned codes */
-    const uint32_t* tile_fi;     /* [T*64] file index of each tile slot or SA_INVALID_FI */
-    const uint8_t* tile_len;     /* [T*64] */
-    const uint8_t* tile_maxlen;  /* [T] */
+    const uint16_t* len_fo;      /* [N] */
+    const uint8_t* codes_t;      /* [64 pos][npad] residue codes in bucket order, position-major */
+    const uint32_t* fi_sorted;   /* [npad] file index of each bucket-order slot */
+    const uint16_t* len_sorted;  /* [npad] */
+    const uint32_t* bucket_base; /* [nb+1] first bucket-order slot of each bucket */
+    const uint32_t* cursor;      /* [N][nb] entries of bucket b with file index <= p */
+    uint32_t nb;
+    uint32_t npad;               /* row pitch of codes_t */
     const int32_t* sprime;       /* [21][32] S[a][b] - 2*gap; row 20 and columns >= 20 are 0 */
     const SaItem* items;
     uint32_t nitems;

@@ -26,7 +26,7 @@
 // substitution scores are expanded once into an LDS "query profile"
 // prof[b][c] = S'[a_c][b], so lane l fetches the scores of four columns with
 // one ds_read_b128 indexed by its own row residue b.  Lanes hold 64 different
-// second sequences taken from one length bucket.
+// second sequences: 64 consecutive entries of p's valid list (bucket order).
 // ADJACENT mode: lane l aligns file rows (k+l, k+l+1); scores are looked up in
 // an LDS copy of S'.
 #include <hip/hip_runtime.h>
@@ -186,7 +186,7 @@ __device__ __forceinline__ void traceback(const int lane, const int maxlen, cons
 
     // Nothing loaded here is used before process(): every request of a chunk (and
     // of the two chunks after it) is in flight at once.  Row indices past the end
-    // of the tile are clamped, so the requests need no guard.
+    // of the longest sequence are clamped, so the requests need no guard.
     auto load_chunk = [&](int ch, SaChunk& ck) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -339,18 +339,29 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_kernel(const Sa
             int bstep;
             const uint8_t* acol = nullptr;   // ADJACENT: slot of sequence 1 (for match counting)
             if (MODE == SA_MODE_TRI) {
-                const uint32_t tile = item.tile_begin + task;
-                const uint32_t q = tile * 64 + lane;
-                const uint32_t fiq = P.tile_fi[q];
-                active = fiq != SA_INVALID_FI && fiq > item.p;
+                // 64 consecutive entries of p's valid list; the scan over buckets is wave-uniform
+                const uint32_t vbase = item.v0 + task * 64;
+                const uint32_t vl = vbase + lane;
+                const uint32_t nvalid = P.nseq - 1 - item.p;
+                active = vl < nvalid;
                 if (!__any(active)) continue;
-                lenq = active ? P.tile_len[q] : 0;
+                uint32_t sidx = 0, cum = item.c0;
+                const uint32_t* cur_row = P.cursor + (size_t)item.p * P.nb;
+                for (uint32_t b = item.b0; b < P.nb; b++) {
+                    const uint32_t first = P.bucket_base[b] + cur_row[b];
+                    const uint32_t cnt = P.bucket_base[b + 1] - first;
+                    if (vl >= cum && vl < cum + cnt) sidx = first + (vl - cum);
+                    cum += cnt;
+                    if (cum > vbase + 63) break;
+                }
+                const uint32_t fiq = P.fi_sorted[sidx];
+                lenq = active ? P.len_sorted[sidx] : 0;
                 lenp = lenp_u;
-                maxlen = P.tile_maxlen[tile];
+                maxlen = __builtin_amdgcn_readfirstlane(wave_max(lenq));
                 gend = (lenp_u + 3) >> 2;
                 rel = fiq - item.p - 1;
-                brow = P.tiles + (size_t)tile * 4096 + lane;
-                bstep = 64;
+                brow = P.codes_t + sidx;
+                bstep = (int)P.npad;
             } else {
                 active = (uint32_t)lane < item.count;
                 const uint32_t s1 = item.p + (active ? lane : 0);
@@ -385,7 +396,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_kernel(const Sa
             for (int c = 0; c < SA_LP; c++) { R[c] = 0; Q[c] = 0; }
             uint32_t alo = 0, ahi = 0, blo = 0, bhi = 0;
 
-            // rows past the end of a sequence read padding (tiles and slots are 64 positions long)
+            // rows past the end of a sequence read padding (codes_t and the slots are 64 positions long)
             auto residue = [&](int r) -> int { return (int)brow[min(r, SA_LP - 1) * bstep]; };
             auto store_dirs = [&](int r) {
                 if (r >= split) {

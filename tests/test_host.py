@@ -119,16 +119,17 @@ def test_expand_record_rejects_garbage():
         al.expand(rec, 0, 1)
 
 
-def _pairs_of_items(items, slots, schedule):
+def _pairs_of_items(items, order, schedule):
     out = []
-    for p, tile_begin, count, _ in items.tolist():
+    valid_cache = {}
+    for p, v0, count, _b0, _c0, _x, _y, _z in items.tolist():
         if schedule == sa.ADJACENT:
             out.extend((p + l, p + l + 1) for l in range(count))
         else:
-            for tile in range(tile_begin, tile_begin + count):
-                for fi in slots[tile * 64 : tile * 64 + 64].tolist():
-                    if fi != 0xFFFFFFFF and fi > p:
-                        out.append((p, fi))
+            if p not in valid_cache:
+                valid_cache = {p: [fi for fi in order if fi > p]}
+            valid = valid_cache[p]
+            out.extend((p, fi) for fi in valid[v0 : v0 + 64 * count])
     return out
 
 
@@ -137,13 +138,13 @@ def test_work_items_cover_every_pair_once(n, lo, hi):
     seqs, _ = synth.generate(n, lo, hi, seed=n)
     al = sa.Aligner(device=sa.DEVICE_NONE)
     al.upload(seqs)
-    slots = al.tile_slots()
-    assert sorted(x for x in slots.tolist() if x != 0xFFFFFFFF) == list(range(n))
+    order = al.bucket_order().tolist()
+    assert sorted(order) == list(range(n))
     for schedule in (sa.ADJACENT, sa.TRIANGULAR):
         rows = al.rows(schedule)
         cuts = sorted({0, rows // 3, rows // 2, rows})
         for r0, r1 in zip(cuts[:-1], cuts[1:]):
-            got = sorted(_pairs_of_items(al.work_items(schedule, r0, r1), slots, schedule))
+            got = sorted(_pairs_of_items(al.work_items(schedule, r0, r1), order, schedule))
             if schedule == sa.ADJACENT:
                 want = [(k, k + 1) for k in range(r0, r1)]
             else:
