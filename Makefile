@@ -15,8 +15,8 @@ MAIN    := sequencealigner_amd/sa_main
 lib: $(LIB) $(MAIN)
 $(MAIN): $(CSRC)/sa_main.cpp $(LIB)
 	$(HIPCC) -O2 -std=c++17 -Wall -o $@ $(CSRC)/sa_main.cpp -Lsequencealigner_amd -lsa_hip -Wl,-rpath,'$$ORIGIN'
-$(LIB): $(CSRC)/sa_kernels.hip $(CSRC)/sa_api.cpp $(CSRC)/sa_host.cpp $(CSRC)/sa_device.h include/sa_hip.h include/sa_host.h
-	$(HIPCC) $(HIPFLAGS) -shared -pthread -o $@ $(CSRC)/sa_kernels.hip $(CSRC)/sa_api.cpp $(CSRC)/sa_host.cpp
+$(LIB): $(CSRC)/sa_kernel_common.h $(CSRC)/sa_kernels.hip $(CSRC)/sa_kernels_long.hip $(CSRC)/sa_api.cpp $(CSRC)/sa_host.cpp $(CSRC)/sa_device.h include/sa_hip.h include/sa_host.h
+	$(HIPCC) $(HIPFLAGS) -shared -pthread -o $@ $(CSRC)/sa_kernels.hip $(CSRC)/sa_kernels_long.hip $(CSRC)/sa_api.cpp $(CSRC)/sa_host.cpp
 
 oracle:
 	$(MAKE) -C oracle all

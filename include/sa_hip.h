@@ -39,7 +39,8 @@ typedef struct sa_ctx sa_ctx;
 #define SA_SCHEDULE_TRIANGULAR 1
 
 #define SA_ALPHABET "ARNDCQEGHILKMFPSTWYV"   /* include/scoring.h:6 */
-#define SA_MAX_PEPTIDE_LEN 64
+#define SA_MAX_PEPTIDE_LEN 64      /* up to here the pair-per-lane register kernel runs */
+#define SA_MAX_SEQ_LEN 4096         /* longest sequence the library takes (strip kernel above 64) */
 /* sa_init device: a context without a GPU.  It answers schedule arithmetic and
  * builds work lists (for tests of the host logic); every compute call on it fails
  * with SA_ERR_STATE.  It is not a CPU implementation of anything. */
@@ -92,6 +93,7 @@ uint64_t sa_pair_index(const sa_ctx* ctx, int schedule, uint64_t row);      /* c
 uint64_t sa_pair_count(const sa_ctx* ctx, int schedule, uint64_t row_begin, uint64_t row_end);
 uint64_t sa_cell_count(const sa_ctx* ctx, int schedule, uint64_t row_begin, uint64_t row_end); /* sum len1*len2 */
 uint32_t sa_record_stride(const sa_ctx* ctx);                               /* bytes per result record */
+uint32_t sa_record_row_bytes(const sa_ctx* ctx);                            /* 1, or 2 when a sequence is longer than 64 */
 /* split [0, rows) into `parts` contiguous row ranges of near-equal cell count;
  * bounds receives parts+1 row indices */
 int sa_shard_rows(const sa_ctx* ctx, int schedule, uint32_t parts, uint64_t* bounds);
@@ -135,8 +137,9 @@ int sa_debug_bucket_order(sa_ctx* ctx, uint32_t* file_index, uint64_t cap, uint6
 
 /* ---- records -> what the reference's Alignment holds (host only, no GPU).
  * seq1/seq2 are the ASCII sequences of the pair; a1/a2 receive the aligned
- * strings (columns+1 bytes each, NUL-terminated). */
-int sa_expand_record(const uint8_t* record, uint32_t stride, const char* seq1, uint32_t len1,
+ * strings (columns+1 bytes each, NUL-terminated); stride and row_bytes are the
+ * context's sa_record_stride / sa_record_row_bytes. */
+int sa_expand_record(const uint8_t* record, uint32_t stride, uint32_t row_bytes, const char* seq1, uint32_t len1,
                      const char* seq2, uint32_t len2, char* a1, char* a2, sa_alignment_stats* st);
 int sa_similarity_bp(int32_t matches, int32_t columns);
 void sa_default_matrix(int32_t S[400]);

@@ -95,6 +95,7 @@ SIGNATURES = {
     "sa_pair_count": (C.c_uint64, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64]),
     "sa_cell_count": (C.c_uint64, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64]),
     "sa_record_stride": (C.c_uint32, [C.c_void_p]),
+    "sa_record_row_bytes": (C.c_uint32, [C.c_void_p]),
     "sa_shard_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.POINTER(C.c_uint64)]),
     "sa_submit": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64]),
     "sa_next": (C.c_int, [C.c_void_p, C.POINTER(_u8p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
@@ -105,7 +106,7 @@ SIGNATURES = {
     "sa_set_tuning": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]),
     "sa_expand_record": (
         C.c_int,
-        [_u8p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_char_p, C.c_char_p,
+        [_u8p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_char_p, C.c_char_p,
          C.POINTER(AlignmentStats)],
     ),
     "sa_debug_phase_cycles": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]),
@@ -248,6 +249,10 @@ class Aligner:
     def stride(self):
         return self._lib.sa_record_stride(self._ctx)
 
+    @property
+    def row_bytes(self):
+        return self._lib.sa_record_row_bytes(self._ctx)
+
     def shard_rows(self, schedule, parts):
         b = (C.c_uint64 * (parts + 1))()
         _check(self._lib.sa_shard_rows(self._ctx, schedule, parts, b))
@@ -333,7 +338,7 @@ class Aligner:
         rec = np.ascontiguousarray(record, dtype=np.uint8)
         _check(
             self._lib.sa_expand_record(
-                rec.ctypes.data_as(_u8p), rec.size, s1, len(s1), s2, len(s2), a1, a2, C.byref(st)
+                rec.ctypes.data_as(_u8p), rec.size, self.row_bytes, s1, len(s1), s2, len(s2), a1, a2, C.byref(st)
             )
         )
         return a1.value, a2.value, st

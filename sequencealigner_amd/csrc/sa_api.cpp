@@ -17,6 +17,7 @@
 
 extern "C" void sa_launch_peptide(int mode, const SaPepParams* p, unsigned grid, unsigned lds_bytes,
                                   hipStream_t stream);
+extern "C" void sa_launch_long(int mode, const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream);
 
 namespace {
 
@@ -113,6 +114,8 @@ struct sa_ctx {
     std::vector<uint64_t> offs_host;
     uint32_t min_seq = 0, max_seq = 0; // shortest / longest uploaded sequence
     uint32_t stride = 80;
+    uint32_t lslot = SA_LP;            // bytes per file-order slot; > 64 selects the long-sequence kernel
+    uint32_t row_bytes = 1;            // bytes per row of sequence 2 in a record
     // bucket order (built on first TRIANGULAR use)
     bool tri_ready = false;
     uint32_t nb = 0, npad = 0;
@@ -120,7 +123,7 @@ struct sa_ctx {
     std::vector<uint32_t> fi_sorted;     // [nseq] file index of each bucket-order slot
     std::vector<uint32_t> cursor;        // [nseq][nb] entries of bucket b with file index <= p
     // device
-    DevBuf d_codes, d_len, d_codes_t, d_fi_sorted, d_len_sorted, d_bucket_base, d_cursor, d_sprime, d_spill, d_phase;
+    DevBuf d_codes, d_len, d_codes_t, d_fi_sorted, d_len_sorted, d_bucket_base, d_cursor, d_sprime, d_spill, d_phase, d_bcol;
     bool phase_timers = false;
     uint32_t spill_grid = 0;
     Work slots[2];
@@ -155,7 +158,7 @@ int ensure_triangular(sa_ctx* c) {
     c->npad = (uint32_t)((n + 63) / 64 * 64 + 64);
     c->fi_sorted.assign(n, 0);
     std::vector<uint16_t> len_sorted(c->npad, 0);
-    std::vector<uint8_t> codes_t((size_t)SA_LP * c->npad, SA_PAD_CODE);
+    std::vector<uint8_t> codes_t((size_t)c->lslot * c->npad, SA_PAD_CODE);
     std::vector<uint32_t> fill(c->bucket_base.begin(), c->bucket_base.end() - 1);
     c->cursor.assign((size_t)n * nb, 0);
     std::vector<uint32_t> running(nb, 0);
@@ -224,18 +227,33 @@ int build_items(sa_ctx* c, int schedule, uint64_t r0, uint64_t r1, std::vector<S
     return SA_OK;
 }
 
-int ensure_spill(sa_ctx* c, uint32_t grid) {
-    if (grid <= c->spill_grid) return SA_OK;
-    int rc = c->d_spill.reserve((size_t)grid * SA_LP * 1024);
-    if (rc) return rc;
-    c->spill_grid = grid;
-    return SA_OK;
+bool is_long(const sa_ctx* c) { return c->lslot > SA_LP; }
+
+// global scratch of one workgroup: direction rows (and, for long sequences, the strip border columns)
+size_t spill_bytes_per_wg(const sa_ctx* c) {
+    if (!is_long(c)) return (size_t)SA_LP * 1024;
+    return (size_t)(c->lslot / 64) * c->lslot * 1024;
 }
 
 uint32_t grid_for(const sa_ctx* c) {
+    if (is_long(c)) {
+        // 194 VGPRs: two waves per SIMD; the direction area of a workgroup is large, keep the total under 32 GiB
+        const uint64_t budget = 32ull << 30;
+        uint64_t g = std::min<uint64_t>((uint64_t)c->ncu * 8, budget / spill_bytes_per_wg(c));
+        return (uint32_t)std::max<uint64_t>(1, g);
+    }
     const uint32_t lds = SA_LDS_FIXED_BYTES + c->lds_dir_bytes;
     uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>(c->wg_per_cu, (160u * 1024u) / lds));
     return (uint32_t)c->ncu * per_cu;
+}
+
+int ensure_spill(sa_ctx* c, uint32_t grid) {
+    if (grid <= c->spill_grid) return SA_OK;
+    int rc = c->d_spill.reserve((size_t)grid * spill_bytes_per_wg(c));
+    if (rc) return rc;
+    if (is_long(c) && (rc = c->d_bcol.reserve((size_t)grid * 2 * c->lslot * 256))) return rc;
+    c->spill_grid = grid;
+    return SA_OK;
 }
 
 // queue the kernels of one row range on the compute stream
@@ -274,8 +292,13 @@ int launch_work(sa_ctx* c, Work& w, bool timed) {
         P.phase_cycles = (unsigned long long*)c->d_phase.p;
     }
     if (timed) SA_HIP_TRY(hipEventRecord(w.t0, c->compute));
-    sa_launch_peptide(w.schedule == SA_SCHEDULE_TRIANGULAR ? 0 : 1, &P, grid,
-                      SA_LDS_FIXED_BYTES + c->lds_dir_bytes, c->compute);
+    P.lslot = c->lslot;
+    P.bcol = (int32_t*)c->d_bcol.p;
+    if (is_long(c))
+        sa_launch_long(w.schedule == SA_SCHEDULE_TRIANGULAR ? 0 : 1, &P, grid, SA_LDS_PROF_BYTES, c->compute);
+    else
+        sa_launch_peptide(w.schedule == SA_SCHEDULE_TRIANGULAR ? 0 : 1, &P, grid,
+                          SA_LDS_FIXED_BYTES + c->lds_dir_bytes, c->compute);
     SA_HIP_TRY(hipGetLastError());
     if (timed) SA_HIP_TRY(hipEventRecord(w.t1, c->compute));
     return SA_OK;
@@ -364,7 +387,7 @@ int sa_similarity_bp(int32_t matches, int32_t columns) {
 
 int sa_init(sa_ctx** out, const int32_t* S, int32_t gap, uint32_t max_seq_len, int device) {
     if (!out || max_seq_len == 0) return SA_ERR_ARG;
-    if (max_seq_len > SA_MAX_PEPTIDE_LEN) return SA_ERR_LENGTH;
+    if (max_seq_len > SA_MAX_LONG_LEN) return SA_ERR_LENGTH;
     if (device == SA_DEVICE_NONE) {
         sa_ctx* h = new (std::nothrow) sa_ctx();
         if (!h) return SA_ERR_NOMEM;
@@ -418,7 +441,7 @@ void sa_destroy(sa_ctx* c) {
     free_work(c->slots[0]); free_work(c->slots[1]); free_work(c->resident);
     c->d_codes.release(); c->d_len.release(); c->d_codes_t.release(); c->d_fi_sorted.release();
     c->d_len_sorted.release(); c->d_bucket_base.release(); c->d_cursor.release(); c->d_sprime.release();
-    c->d_spill.release();
+    c->d_spill.release(); c->d_bcol.release();
     c->d_phase.release();
     if (c->compute) (void)hipStreamDestroy(c->compute);
     if (c->copy) (void)hipStreamDestroy(c->copy);
@@ -452,12 +475,17 @@ int sa_upload(sa_ctx* c, const uint8_t* codes, const uint64_t* offs, const uint3
     c->nseq = nseq;
     c->min_seq = lmin;
     c->max_seq = lmax;
-    c->stride = (SA_REC_HEADER_BYTES + lmax + 15u) & ~15u;
+    const bool lng = lmax > SA_LP;
+    const uint32_t lslot = lng ? (lmax + 63u) / 64u * 64u : SA_LP;
+    if (lslot != c->lslot) c->spill_grid = 0;     // scratch areas are sized by the slot
+    c->lslot = lslot;
+    c->row_bytes = lng ? 2 : 1;
+    c->stride = lng ? (SA_LONG_HEADER_BYTES + 2 * lmax + 15u) & ~15u : (SA_REC_HEADER_BYTES + lmax + 15u) & ~15u;
     c->resident_ready = false;
     c->tri_ready = false;
 
     // file-order slots padded with SA_PAD_CODE (plus two spare slots)
-    std::vector<uint8_t> slots((size_t)(nseq + 2) * SA_LP, SA_PAD_CODE);
+    std::vector<uint8_t> slots((size_t)(nseq + 2) * lslot, SA_PAD_CODE);
     c->len.assign(nseq, 0);
     c->offs_host.assign(offs, offs + nseq);
     uint64_t total = 0;
@@ -465,7 +493,7 @@ int sa_upload(sa_ctx* c, const uint8_t* codes, const uint64_t* offs, const uint3
     c->codes_host.assign(codes, codes + total);
     for (uint64_t s = 0; s < nseq; s++) {
         c->len[s] = (uint16_t)lens[s];
-        memcpy(&slots[(size_t)s * SA_LP], codes + offs[s], lens[s]);
+        memcpy(&slots[(size_t)s * lslot], codes + offs[s], lens[s]);
     }
     c->len_suffix.assign(nseq + 1, 0);
     for (uint64_t s = nseq; s-- > 0;) c->len_suffix[s] = c->len_suffix[s + 1] + c->len[s];
@@ -507,6 +535,7 @@ uint64_t sa_cell_count(const sa_ctx* c, int schedule, uint64_t r0, uint64_t r1) 
 }
 
 uint32_t sa_record_stride(const sa_ctx* c) { return c ? c->stride : 0; }
+uint32_t sa_record_row_bytes(const sa_ctx* c) { return c ? c->row_bytes : 0; }
 
 int sa_shard_rows(const sa_ctx* c, int schedule, uint32_t parts, uint64_t* bounds) {
     if (!c || !bounds || parts == 0) return SA_ERR_ARG;
@@ -650,17 +679,29 @@ int sa_debug_phase_cycles(sa_ctx* c, int enable, uint64_t totals[8]) {
     return SA_OK;
 }
 
-int sa_expand_record(const uint8_t* rec, uint32_t stride, const char* seq1, uint32_t len1, const char* seq2,
-                     uint32_t len2, char* a1, char* a2, sa_alignment_stats* st) {
-    if (!rec || !seq1 || !seq2 || !a1 || !a2 || !st) return SA_ERR_ARG;
-    if (stride < SA_REC_HEADER_BYTES || len2 > stride - SA_REC_HEADER_BYTES) return SA_ERR_RECORD;
-    int32_t score; uint16_t matches, gaps;
-    memcpy(&score, rec, 4); memcpy(&matches, rec + 4, 2); memcpy(&gaps, rec + 6, 2);
-    const uint8_t* body = rec + SA_REC_HEADER_BYTES;
+int sa_expand_record(const uint8_t* rec, uint32_t stride, uint32_t row_bytes, const char* seq1, uint32_t len1,
+                     const char* seq2, uint32_t len2, char* a1, char* a2, sa_alignment_stats* st) {
+    if (!rec || !seq1 || !seq2 || !a1 || !a2 || !st || (row_bytes != 1 && row_bytes != 2)) return SA_ERR_ARG;
+    const uint32_t header = row_bytes == 1 ? SA_REC_HEADER_BYTES : SA_LONG_HEADER_BYTES;
+    if (stride < header || (uint64_t)len2 * row_bytes > stride - header) return SA_ERR_RECORD;
+    int32_t score; uint32_t matches, gaps;
+    memcpy(&score, rec, 4);
+    if (row_bytes == 1) {
+        uint16_t m16, g16;
+        memcpy(&m16, rec + 4, 2); memcpy(&g16, rec + 6, 2);
+        matches = m16; gaps = g16;
+    } else {
+        memcpy(&matches, rec + 4, 4); memcpy(&gaps, rec + 8, 4);
+    }
+    if (gaps > len2 || matches > len1) return SA_ERR_RECORD;
+    const uint8_t* body = rec + header;
     const uint32_t columns = len1 + gaps;     // every column holds a residue of sequence 1 or one of its gaps
     uint32_t pos = columns, j = len1, ups = 0;
-    for (uint32_t k = 0; k < len2; k++) {
-        const uint32_t i = len2 - k, run = body[i - 1] >> 1, up = body[i - 1] & 1;
+    for (uint32_t i = len2; i >= 1; i--) {
+        uint32_t v;
+        if (row_bytes == 1) v = body[i - 1];
+        else { uint16_t v16; memcpy(&v16, body + 2 * (size_t)(i - 1), 2); v = v16; }
+        const uint32_t run = v >> 1, up = v & 1;
         if (run > j || pos < run + 1) return SA_ERR_RECORD;
         for (uint32_t x = 0; x < run; x++) { --pos; a1[pos] = seq1[--j]; a2[pos] = '-'; }
         --pos;
@@ -675,10 +716,10 @@ int sa_expand_record(const uint8_t* rec, uint32_t stride, const char* seq1, uint
     a1[columns] = a2[columns] = '\0';
     st->score = score;
     st->columns = (int32_t)columns;
-    st->matches = matches;
-    st->gaps = gaps;
-    st->mismatches = (int32_t)columns - matches - gaps;
-    st->similarity_bp = sa_similarity_bp(matches, (int32_t)columns);
+    st->matches = (int32_t)matches;
+    st->gaps = (int32_t)gaps;
+    st->mismatches = (int32_t)columns - (int32_t)matches - (int32_t)gaps;
+    st->similarity_bp = sa_similarity_bp((int32_t)matches, (int32_t)columns);
     return SA_OK;
 }
 

@@ -61,6 +61,11 @@ typedef struct {
  *   bit 0     = how the row was left: 0 = DIAG, 1 = UP.
  * Whatever is left of sequence 1 after row 1 is consumed by LEFT moves. */
 #define SA_REC_HEADER_BYTES 8
+/* Long sequences (more than 64 residues): 16-byte header {int32 score, uint32 matches,
+ * uint32 gaps, uint32 0}, then one uint16 per row of sequence 2 with the same meaning
+ * (bits 15..1 = LEFT moves, bit 0 = DIAG/UP). */
+#define SA_LONG_HEADER_BYTES 16
+#define SA_MAX_LONG_LEN 4096
 
 typedef struct {
     const uint8_t* codes_fo;     /* [N][64] residue codes padded with SA_PAD_CODE, file order */
@@ -86,6 +91,9 @@ typedef struct {
     int32_t gap;
     uint32_t lds_dir_bytes;      /* LDS bytes for direction rows (multiple of 1024) */
     unsigned long long* phase_cycles;  /* optional [grid][8] shader-cycle totals per phase, or NULL */
+    /* long-sequence kernel only */
+    uint32_t lslot;              /* bytes per file-order slot = rows of codes_t = row capacity (multiple of 64) */
+    int32_t* bcol;               /* per workgroup 2 x lslot x 64: last DP column of a strip, for the next strip */
 } SaPepParams;
 
 #endif

@@ -328,7 +328,7 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
     auto cleanup = [&]() { for (auto c : ctx) sa_destroy(c); };
     // the reference's buffers hold sequences shorter than MAX_SEQ_LEN (NUL included, include/thread.h:27-29)
     const uint32_t max_len = st->max_seq_len ? st->max_seq_len - 1 : 0;
-    if (max_len == 0 || max_len > SA_MAX_PEPTIDE_LEN) { err = "MAX_SEQ_LEN must be between 2 and 65"; return fail(SA_ERR_LENGTH); }
+    if (max_len == 0 || max_len > SA_MAX_SEQ_LEN) { err = "MAX_SEQ_LEN must be between 2 and 4097"; return fail(SA_ERR_LENGTH); }
     for (int d = 0; d < ndev; d++) {
         rc = sa_init(&ctx[(size_t)d], nullptr, st->gap_penalty, max_len, st->devices[d]);
         if (rc) { cleanup(); return fail(rc); }
@@ -381,6 +381,7 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
         rep->pairs = sa_pair_count(ctx[0], schedule, 0, rows);
         rep->cells = sa_cell_count(ctx[0], schedule, 0, rows);
         const uint32_t stride = sa_record_stride(ctx[0]);
+        const uint32_t row_bytes = sa_record_row_bytes(ctx[0]);
 
         // chunks of whole schedule rows; chunk k goes to device k % ndev, results are consumed in chunk order
         uint64_t cap = st->pairs_per_submit ? st->pairs_per_submit : (uint64_t)st->batch_size * 64;
@@ -437,7 +438,7 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
                         const Row& r1 = tab.rows[i];
                         const Row& r2 = tab.rows[j];
                         sa_alignment_stats s;
-                        if (sa_expand_record(recs + q * stride, stride, r1.seq, r1.len, r2.seq, r2.len, a1.data(), a2.data(), &s) != SA_OK) {
+                        if (sa_expand_record(recs + q * (size_t)stride, stride, row_bytes, r1.seq, r1.len, r2.seq, r2.len, a1.data(), a2.data(), &s) != SA_OK) {
                             bad.store(1);
                             break;
                         }

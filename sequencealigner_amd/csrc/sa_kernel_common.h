@@ -1,0 +1,140 @@
+// sa_kernel_common.h -- device code shared by the peptide kernel (sa_kernels.hip)
+// and the long-sequence kernel (sa_kernels_long.hip): the DP cell, one row of a
+// 64-column strip in both operand modes, and small wave helpers.
+#ifndef SA_KERNEL_COMMON_H
+#define SA_KERNEL_COMMON_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sa_device.h"
+
+#define SA_MODE_TRI 0
+#define SA_MODE_ADJ 1
+
+__device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
+
+// (hi:lo) >> sh, low 32 bits: shifting in the sign bit of lo with sh = 31
+__device__ __forceinline__ uint32_t shift_in_sign(uint32_t acc, int v) {
+    return __builtin_amdgcn_alignbit(acc, (uint32_t)v, 31);
+}
+
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_min(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// One DP cell.  up/diag come from the previous row's bank, left from this row's;
+// for column 0 they are diag0 / left0 (0 on the matrix border, the last column of
+// the previous 64-column strip otherwise).  The two direction bits are the sign
+// bits of (m - h) and (up - h).
+#define SA_CELL(IN, OUT, C, S, PA, PB)                                     \
+    {                                                                      \
+        const int diag_ = ((C) == 0) ? diag0 : IN[((C) == 0) ? 0 : (C) - 1];   \
+        const int left_ = ((C) == 0) ? left0 : OUT[((C) == 0) ? 0 : (C) - 1];  \
+        const int up_ = IN[C];                                             \
+        const int m_ = diag_ + (S);                                        \
+        const int h_ = max3i(m_, up_, left_);                              \
+        PA = shift_in_sign(PA, m_ - h_);                                   \
+        PB = shift_in_sign(PB, up_ - h_);                                  \
+        OUT[C] = h_;                                                       \
+    }
+
+// Four columns of a TRIANGULAR row.  CUR holds their substitution scores; the
+// scores of the next four columns are requested first so that the LDS latency
+// is covered by the 24 arithmetic instructions of this group (a row of the
+// profile is 68 dwords apart from the next, so the request after the last group
+// stays inside the row's padding).  Rows end early: gend = ceil(len1 / 4).
+#define SA_GROUP_TRI(G, CUR, NXT, PA, PB)                                          \
+    NXT = *reinterpret_cast<const int4*>(row_base + 4 * ((G) + 1));                \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+    SA_CELL(IN, OUT, 4 * (G) + 0, CUR.x, PA, PB)                                   \
+    SA_CELL(IN, OUT, 4 * (G) + 1, CUR.y, PA, PB)                                   \
+    SA_CELL(IN, OUT, 4 * (G) + 2, CUR.z, PA, PB)                                   \
+    SA_CELL(IN, OUT, 4 * (G) + 3, CUR.w, PA, PB)                                   \
+    if (gend == (G) + 1) return;
+
+// One DP row of the TRIANGULAR kernel: IN = previous row, OUT = this row,
+// columns 0 .. 4*gend-1 (gend is wave-uniform).  sc0: in = scores of columns
+// 0..3 for this row, out = the same for the next row (requested at the top of
+// the row, used one row later).
+__device__ __forceinline__ void fill_row_tri(const int (&IN)[SA_LP], int (&OUT)[SA_LP], const int gend,
+                                             const int diag0, const int left0,
+                                             const int32_t* __restrict__ row_base,
+                                             const int32_t* __restrict__ next_row_base, int4& sc0,
+                                             uint32_t& alo, uint32_t& ahi, uint32_t& blo, uint32_t& bhi) {
+    int4 scE = sc0, scO;
+    sc0 = *reinterpret_cast<const int4*>(next_row_base);
+    SA_GROUP_TRI(0, scE, scO, alo, blo)
+    SA_GROUP_TRI(1, scO, scE, alo, blo)
+    SA_GROUP_TRI(2, scE, scO, alo, blo)
+    SA_GROUP_TRI(3, scO, scE, alo, blo)
+    SA_GROUP_TRI(4, scE, scO, alo, blo)
+    SA_GROUP_TRI(5, scO, scE, alo, blo)
+    SA_GROUP_TRI(6, scE, scO, alo, blo)
+    SA_GROUP_TRI(7, scO, scE, alo, blo)
+    SA_GROUP_TRI(8, scE, scO, ahi, bhi)
+    SA_GROUP_TRI(9, scO, scE, ahi, bhi)
+    SA_GROUP_TRI(10, scE, scO, ahi, bhi)
+    SA_GROUP_TRI(11, scO, scE, ahi, bhi)
+    SA_GROUP_TRI(12, scE, scO, ahi, bhi)
+    SA_GROUP_TRI(13, scO, scE, ahi, bhi)
+    SA_GROUP_TRI(14, scE, scO, ahi, bhi)
+    SA_GROUP_TRI(15, scO, scE, ahi, bhi)
+}
+
+// One DP row of the ADJACENT kernel (every lane has its own column sequence):
+// scores come from an LDS copy of S', row selected by the row residue, entry by
+// the column residue (a4 = 4 * residue code).
+__device__ __forceinline__ void fill_row_adj(const int (&IN)[SA_LP], int (&OUT)[SA_LP], const int gend,
+                                             const int diag0, const int left0,
+                                             const int32_t* __restrict__ row_base, const int (&a4)[SA_LP],
+                                             uint32_t& alo, uint32_t& ahi, uint32_t& blo, uint32_t& bhi) {
+    const char* rb = reinterpret_cast<const char*>(row_base);
+#pragma unroll
+    for (int g = 0; g < SA_LP / 4; g++) {
+        if (g < gend) {   // wave-uniform
+            const int s0 = *reinterpret_cast<const int32_t*>(rb + a4[4 * g + 0]);
+            const int s1 = *reinterpret_cast<const int32_t*>(rb + a4[4 * g + 1]);
+            const int s2 = *reinterpret_cast<const int32_t*>(rb + a4[4 * g + 2]);
+            const int s3 = *reinterpret_cast<const int32_t*>(rb + a4[4 * g + 3]);
+            if (g < 8) {
+                SA_CELL(IN, OUT, 4 * g + 0, s0, alo, blo)
+                SA_CELL(IN, OUT, 4 * g + 1, s1, alo, blo)
+                SA_CELL(IN, OUT, 4 * g + 2, s2, alo, blo)
+                SA_CELL(IN, OUT, 4 * g + 3, s3, alo, blo)
+            } else {
+                SA_CELL(IN, OUT, 4 * g + 0, s0, ahi, bhi)
+                SA_CELL(IN, OUT, 4 * g + 1, s1, ahi, bhi)
+                SA_CELL(IN, OUT, 4 * g + 2, s2, ahi, bhi)
+                SA_CELL(IN, OUT, 4 * g + 3, s3, ahi, bhi)
+            }
+        }
+    }
+}
+
+// value of register column `col` (wave-uniform) of a row bank
+#define SA_PICK_CASE(C) case C: v = BANK[C]; break;
+__device__ __forceinline__ int pick_column(const int (&BANK)[SA_LP], const int col) {
+    int v = 0;
+    switch (col) {
+        SA_PICK_CASE(0) SA_PICK_CASE(1) SA_PICK_CASE(2) SA_PICK_CASE(3) SA_PICK_CASE(4) SA_PICK_CASE(5) SA_PICK_CASE(6) SA_PICK_CASE(7)
+        SA_PICK_CASE(8) SA_PICK_CASE(9) SA_PICK_CASE(10) SA_PICK_CASE(11) SA_PICK_CASE(12) SA_PICK_CASE(13) SA_PICK_CASE(14) SA_PICK_CASE(15)
+        SA_PICK_CASE(16) SA_PICK_CASE(17) SA_PICK_CASE(18) SA_PICK_CASE(19) SA_PICK_CASE(20) SA_PICK_CASE(21) SA_PICK_CASE(22) SA_PICK_CASE(23)
+        SA_PICK_CASE(24) SA_PICK_CASE(25) SA_PICK_CASE(26) SA_PICK_CASE(27) SA_PICK_CASE(28) SA_PICK_CASE(29) SA_PICK_CASE(30) SA_PICK_CASE(31)
+        SA_PICK_CASE(32) SA_PICK_CASE(33) SA_PICK_CASE(34) SA_PICK_CASE(35) SA_PICK_CASE(36) SA_PICK_CASE(37) SA_PICK_CASE(38) SA_PICK_CASE(39)
+        SA_PICK_CASE(40) SA_PICK_CASE(41) SA_PICK_CASE(42) SA_PICK_CASE(43) SA_PICK_CASE(44) SA_PICK_CASE(45) SA_PICK_CASE(46) SA_PICK_CASE(47)
+        SA_PICK_CASE(48) SA_PICK_CASE(49) SA_PICK_CASE(50) SA_PICK_CASE(51) SA_PICK_CASE(52) SA_PICK_CASE(53) SA_PICK_CASE(54) SA_PICK_CASE(55)
+        SA_PICK_CASE(56) SA_PICK_CASE(57) SA_PICK_CASE(58) SA_PICK_CASE(59) SA_PICK_CASE(60) SA_PICK_CASE(61) SA_PICK_CASE(62) SA_PICK_CASE(63)
+        default: break;
+    }
+    return v;
+}
+
+#endif
