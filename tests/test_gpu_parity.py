@@ -36,7 +36,7 @@ def _csv_case(tmp_path, seqs, labels, schedule, gap=-4, **kw):
     synth.write_csv(str(src), seqs, labels)
     want = tmp_path / "oracle.csv"
     got = tmp_path / "gpu.csv"
-    oracle_lib.run_file(str(src), str(want), schedule, threads=4, gap=gap)
+    oracle_lib.run_file(str(src), str(want), schedule, threads=8, gap=gap)
     rep = sa.run_csv(str(src), str(got), schedule, gap_penalty=gap, **kw)
     assert got.read_bytes() == want.read_bytes()
     return rep
@@ -128,6 +128,38 @@ def test_asymmetric_matrix_and_length_64():
     _check_pairs(al, rec, _tri_pairs(n, 0, n - 1), gap=-3, matrix=matrix)
     rec = al.align(sa.ADJACENT)
     _check_pairs(al, rec, [(k, k + 1) for k in range(n - 1)], gap=-3, matrix=matrix)
+
+
+@pytest.mark.parametrize("schedule", [sa.ADJACENT, sa.TRIANGULAR])
+@pytest.mark.parametrize(
+    "n,lo,hi,seed",
+    [(120, 1, 300, 6), (64, 128, 128, 7), (70, 60, 70, 8), (100, 300, 1000, 2), (300, 65, 66, 9)],
+)
+def test_long_sequences_csv_equal_oracle(tmp_path, schedule, n, lo, hi, seed):
+    """Sequences longer than 64 residues run through the 64-column strip kernel."""
+    seqs, labels = synth.generate(n, lo, hi, seed)
+    _csv_case(tmp_path, seqs, labels, schedule, max_seq_len=hi + 1)
+
+
+def test_long_sequences_low_complexity_and_gap_runs(tmp_path):
+    rng = random.Random(15)
+    seqs = [("".join(rng.choice("AW") for _ in range(rng.randint(1, 400)))).encode() for _ in range(60)]
+    seqs += [b"A" * 700, b"W" * 2, b"A" * 129, b"AW" * 200]
+    labels = [k & 1 for k in range(len(seqs))]
+    _csv_case(tmp_path, seqs, labels, sa.TRIANGULAR, max_seq_len=701)
+    _csv_case(tmp_path, seqs, labels, sa.ADJACENT, gap=-1, max_seq_len=701)
+
+
+def test_longest_supported_sequences():
+    rng = random.Random(19)
+    seqs = ["".join(rng.choice(ALPHABET) for _ in range(n)) for n in (4096, 4095, 3000, 4096, 70)]
+    al = sa.Aligner(max_seq_len=4096)
+    al.upload(seqs)
+    assert al.row_bytes == 2
+    rec = al.align(sa.TRIANGULAR)
+    _check_pairs(al, rec, _tri_pairs(len(seqs), 0, len(seqs) - 1))
+    rec = al.align(sa.ADJACENT)
+    _check_pairs(al, rec, [(k, k + 1) for k in range(len(seqs) - 1)])
 
 
 def test_row_ranges_and_shards_concatenate_to_the_whole():

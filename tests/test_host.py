@@ -56,6 +56,9 @@ def test_upload_rejects_empty_and_too_long():
     with pytest.raises(sa.SaError):
         al.upload(["A" * 64, "ARND"])
     al.upload(["A" * 63, "ARND"])
+    assert al.row_bytes == 1
+    with pytest.raises(sa.SaError):
+        sa.Aligner(device=sa.DEVICE_NONE, max_seq_len=4097)
 
 
 @pytest.mark.parametrize(
@@ -74,14 +77,20 @@ def test_similarity_equals_oracle_everywhere():
             assert lib.sa_similarity_bp(m, p) == orc.sa_oracle_similarity_bp(m, p)
 
 
-def _record_from_alignment(a1, a2, score, stride):
-    """Encode an alignment the way the kernel does: one byte per row of sequence 2."""
+def _record_from_alignment(a1, a2, score, stride, row_bytes=1):
+    """Encode an alignment the way the kernels do: one byte (or uint16) per row of sequence 2."""
     rec = np.zeros(stride, dtype=np.uint8)
     matches = sum(1 for x, y in zip(a1, a2) if x == y)
     gaps = sum(1 for x, y in zip(a1, a2) if x != y and x == "-")
     rec[0:4] = np.frombuffer(np.int32(score).tobytes(), dtype=np.uint8)
-    rec[4:6] = np.frombuffer(np.uint16(matches).tobytes(), dtype=np.uint8)
-    rec[6:8] = np.frombuffer(np.uint16(gaps).tobytes(), dtype=np.uint8)
+    if row_bytes == 1:
+        rec[4:6] = np.frombuffer(np.uint16(matches).tobytes(), dtype=np.uint8)
+        rec[6:8] = np.frombuffer(np.uint16(gaps).tobytes(), dtype=np.uint8)
+        header = 8
+    else:
+        rec[4:8] = np.frombuffer(np.uint32(matches).tobytes(), dtype=np.uint8)
+        rec[8:12] = np.frombuffer(np.uint32(gaps).tobytes(), dtype=np.uint8)
+        header = 16
     # walk the columns from the end: LEFT moves (gap in sequence 2) accumulate until a column consumes a row
     row = sum(1 for y in a2 if y != "-")
     run = 0
@@ -89,7 +98,11 @@ def _record_from_alignment(a1, a2, score, stride):
         if y == "-":
             run += 1
         else:
-            rec[8 + row - 1] = run * 2 + (1 if x == "-" else 0)
+            v = run * 2 + (1 if x == "-" else 0)
+            if row_bytes == 1:
+                rec[header + row - 1] = v
+            else:
+                rec[header + 2 * (row - 1) : header + 2 * row] = np.frombuffer(np.uint16(v).tobytes(), dtype=np.uint8)
             run = 0
             row -= 1
     return rec
@@ -104,6 +117,23 @@ def test_expand_record_round_trip_against_oracle():
     for k in range(len(seqs) - 1):
         o1, o2, r = oracle_lib.align(seqs[k], seqs[k + 1])
         rec = _record_from_alignment(o1.decode(), o2.decode(), r.score, stride)
+        a1, a2, st = al.expand(rec, k, k + 1)
+        assert (a1, a2) == (o1, o2)
+        assert (st.score, st.columns, st.matches, st.mismatches, st.gaps, st.similarity_bp) == (
+            r.score, r.columns, r.matches, r.mismatches, r.gaps, r.similarity_bp)
+
+
+def test_expand_long_record_round_trip_against_oracle():
+    rng = random.Random(4)
+    al = sa.Aligner(device=sa.DEVICE_NONE, max_seq_len=700)
+    seqs = ["".join(rng.choice(ALPHABET) for _ in range(rng.choice([1, 64, 65, 130, 333, 700]))) for _ in range(40)]
+    seqs.append("A" * 500)       # long runs of gaps against the next one
+    seqs.append("W" * 3)
+    al.upload(seqs)
+    assert al.row_bytes == 2 and al.stride >= 16 + 2 * 700
+    for k in range(len(seqs) - 1):
+        o1, o2, r = oracle_lib.align(seqs[k], seqs[k + 1])
+        rec = _record_from_alignment(o1.decode(), o2.decode(), r.score, al.stride, row_bytes=2)
         a1, a2, st = al.expand(rec, k, k + 1)
         assert (a1, a2) == (o1, o2)
         assert (st.score, st.columns, st.matches, st.mismatches, st.gaps, st.similarity_bp) == (
