@@ -37,6 +37,8 @@ WORKLOADS = {
     "peptides50k": (50000, 6, 50, 1, "synthetic 50k peptides len 6-50 seed 1, all-vs-all (BASELINE configs[2])"),
     "peptides20k": (20000, 6, 50, 1, "synthetic 20k peptides len 6-50 seed 1, all-vs-all"),
     "peptides4k": (4000, 6, 50, 1, "synthetic 4k peptides len 6-50 seed 1, all-vs-all"),
+    "proteins10k": (10000, 300, 1000, 2, "synthetic 10k proteins len 300-1000 seed 2, all-vs-all (BASELINE configs[4])"),
+    "proteins2k": (2000, 300, 1000, 2, "first 2000 of the synthetic proteins len 300-1000 seed 2, all-vs-all"),
 }
 
 
@@ -96,12 +98,33 @@ def cpu_baseline(seqs, labels, sample_n):
     }
 
 
+def side_measurement(name, device):
+    """A second workload measured after the timed region (not part of `value`): the
+    long-sequence kernel on a prefix of the protein set of BASELINE configs[4]."""
+    n, lo, hi, seed, desc = WORKLOADS[name]
+    seqs, _ = synth.generate(n, lo, hi, seed)
+    al = sa.Aligner(device=device, max_seq_len=hi)
+    al.upload(seqs)
+    rows = al.rows(sa.TRIANGULAR)
+    cells = al.cell_count(sa.TRIANGULAR, 0, rows)
+    pairs = al.pair_count(sa.TRIANGULAR, 0, rows)
+    al.prepare_resident(sa.TRIANGULAR, 0, rows)
+    al.run_resident()
+    ms = [al.run_resident() for _ in range(2)]
+    al.close()
+    k_ms = sum(ms) / len(ms)
+    return {"workload": desc, "pairs": pairs, "cells": cells, "kernel_ms": round(k_ms, 3),
+            "gcups": round(cells / k_ms / 1e6, 1), "pairs_per_s": round(pairs / k_ms * 1e3, 1),
+            "roofline_frac": round(cells * OPS_PER_CELL / (k_ms * 1e-3) / 1e12 / PEAK_TIOPS, 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="peptides50k", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-extra", action="store_true", help="skip the protein side measurement")
     ap.add_argument("--cpu-sample", type=int, default=20000, help="sequences in the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -116,7 +139,7 @@ def main():
 
     n, lo, hi, seed, desc = WORKLOADS[args.workload]
     seqs, labels = synth.generate(n, lo, hi, seed)
-    al = sa.Aligner(device=local_rank)          # raises if the HIP library or the device is missing
+    al = sa.Aligner(device=local_rank, max_seq_len=max(64, hi))   # raises if the HIP library or the device is missing
     al.upload(seqs)
     r0, r1 = shard_for_rank(al, sa.TRIANGULAR, rank, world)
     my_pairs = al.pair_count(sa.TRIANGULAR, r0, r1)
@@ -158,7 +181,7 @@ def main():
                 "pairs": int(total_pairs),
                 "cells": int(total_cells),
                 "schedule": "triangular, contiguous row ranges of equal cell count per GPU",
-                "results": "64-byte record per pair (score, matches, gaps, traceback) left in HBM",
+                "results": f"{al.stride}-byte record per pair (score, matches, gaps, traceback) left in HBM",
             },
             "roofline": {
                 "bound": "valu_int32",
@@ -167,7 +190,7 @@ def main():
                 "unit": "TIOP/s",
                 "frac": round(achieved / PEAK_TIOPS, 4),
                 "traffic": None,
-                "kernel": "sa_peptide_kernel<0>",
+                "kernel": "sa_long_kernel<0>" if hi > 64 else "sa_peptide_kernel<0, 3>",
                 "kernel_ms": round(k_ms, 3),
                 "cells_per_launch": int(my_cells),
                 "ops_per_cell": OPS_PER_CELL,
@@ -175,7 +198,9 @@ def main():
             },
         }
         if world == 1 and args.cpu_sample > 0:
-            out["cpu_baseline"] = cpu_baseline(seqs, labels, min(args.cpu_sample, n))
+            out["cpu_baseline"] = cpu_baseline(seqs, labels, min(args.cpu_sample, n) if hi <= 64 else min(400, n))
+        if world == 1 and args.workload == "peptides50k" and not args.no_extra:
+            out["extra"] = {"proteins2k": side_measurement("proteins2k", local_rank)}
         print(json.dumps(out), flush=True)
     al.close()
     if world > 1:

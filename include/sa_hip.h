@@ -116,9 +116,9 @@ int sa_release(sa_ctx* ctx);
 int sa_prepare_resident(sa_ctx* ctx, int schedule, uint64_t row_begin, uint64_t row_end);
 int sa_run_resident(sa_ctx* ctx, float* kernel_ms);
 int sa_fetch_resident(sa_ctx* ctx, uint64_t first, uint64_t n, uint8_t* dst);
-/* tuning knobs: LDS bytes for traceback rows per wave (multiple of 1024),
- * tiles per work item, workgroups per CU; 0 keeps the current value */
-int sa_set_tuning(sa_ctx* ctx, uint32_t lds_dir_bytes, uint32_t tiles_per_item, uint32_t wg_per_cu);
+/* tuning knobs of the peptide kernel: 64-pair tiles per work item, workgroups (waves)
+ * per CU; 0 keeps the current value */
+int sa_set_tuning(sa_ctx* ctx, uint32_t tiles_per_item, uint32_t wg_per_cu);
 
 /* diagnostic: with enable != 0 the next launches accumulate shader cycles per kernel
  * phase (0 queue fetch, 1 profile build, 2 operand set-up, 3 fill, 4 traceback,

@@ -103,7 +103,7 @@ SIGNATURES = {
     "sa_prepare_resident": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64]),
     "sa_run_resident": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "sa_fetch_resident": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, _u8p]),
-    "sa_set_tuning": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "sa_set_tuning": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     "sa_expand_record": (
         C.c_int,
         [_u8p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_char_p, C.c_char_p,
@@ -258,8 +258,8 @@ class Aligner:
         _check(self._lib.sa_shard_rows(self._ctx, schedule, parts, b))
         return list(b)
 
-    def set_tuning(self, lds_dir_bytes=0, tiles_per_item=0, wg_per_cu=0):
-        _check(self._lib.sa_set_tuning(self._ctx, lds_dir_bytes, tiles_per_item, wg_per_cu))
+    def set_tuning(self, tiles_per_item=0, wg_per_cu=0):
+        _check(self._lib.sa_set_tuning(self._ctx, tiles_per_item, wg_per_cu))
 
     # -- dispatch
     def submit(self, schedule, r0, r1):

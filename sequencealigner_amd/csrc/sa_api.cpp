@@ -101,9 +101,6 @@ struct sa_ctx {
     uint32_t max_len = 64;
     hipStream_t compute = nullptr, copy = nullptr;
     // tuning
-    // Spilling direction rows to the global spill area costs ~3 % (measured), a third wave per SIMD
-    // gains ~6 %: keep the LDS share of a wave small enough for 12 single-wave workgroups per CU.
-    uint32_t lds_dir_bytes = 1024;
     uint32_t tiles_per_item = 8;
     uint32_t wg_per_cu = 12;
     // sequences (host mirror)
@@ -123,7 +120,7 @@ struct sa_ctx {
     std::vector<uint32_t> fi_sorted;     // [nseq] file index of each bucket-order slot
     std::vector<uint32_t> cursor;        // [nseq][nb] entries of bucket b with file index <= p
     // device
-    DevBuf d_codes, d_len, d_codes_t, d_fi_sorted, d_len_sorted, d_bucket_base, d_cursor, d_sprime, d_spill, d_phase, d_bcol;
+    DevBuf d_codes, d_len, d_codes_t, d_fi_sorted, d_len_sorted, d_bucket_base, d_cursor, d_sprime, d_spill, d_phase, d_bcol, d_codes_s;
     bool phase_timers = false;
     uint32_t spill_grid = 0;
     Work slots[2];
@@ -159,6 +156,8 @@ int ensure_triangular(sa_ctx* c) {
     c->fi_sorted.assign(n, 0);
     std::vector<uint16_t> len_sorted(c->npad, 0);
     std::vector<uint8_t> codes_t((size_t)c->lslot * c->npad, SA_PAD_CODE);
+    const bool lng = c->lslot > SA_LP;
+    std::vector<uint8_t> codes_s(lng ? 16 : (size_t)c->npad * SA_LP, SA_PAD_CODE);
     std::vector<uint32_t> fill(c->bucket_base.begin(), c->bucket_base.end() - 1);
     c->cursor.assign((size_t)n * nb, 0);
     std::vector<uint32_t> running(nb, 0);
@@ -169,6 +168,7 @@ int ensure_triangular(sa_ctx* c) {
         len_sorted[slot] = c->len[s];
         const uint8_t* src = c->codes_host.data() + c->offs_host[s];
         for (uint32_t i = 0; i < c->len[s]; i++) codes_t[(size_t)i * c->npad + slot] = src[i];
+        if (!lng) memcpy(&codes_s[(size_t)slot * SA_LP], src, c->len[s]);
         running[b]++;
         memcpy(&c->cursor[(size_t)s * nb], running.data(), nb * sizeof(uint32_t));
     }
@@ -177,6 +177,8 @@ int ensure_triangular(sa_ctx* c) {
         std::vector<uint32_t> fi_pad(c->npad, SA_INVALID_FI);
         memcpy(fi_pad.data(), c->fi_sorted.data(), n * 4);
         if ((rc = c->d_codes_t.reserve(codes_t.size()))) return rc;
+        if ((rc = c->d_codes_s.reserve(codes_s.size()))) return rc;
+        SA_HIP_TRY(hipMemcpy(c->d_codes_s.p, codes_s.data(), codes_s.size(), hipMemcpyHostToDevice));
         if ((rc = c->d_fi_sorted.reserve(fi_pad.size() * 4))) return rc;
         if ((rc = c->d_len_sorted.reserve(len_sorted.size() * 2))) return rc;
         if ((rc = c->d_bucket_base.reserve(c->bucket_base.size() * 4))) return rc;
@@ -242,7 +244,7 @@ uint32_t grid_for(const sa_ctx* c) {
         uint64_t g = std::min<uint64_t>((uint64_t)c->ncu * 8, budget / spill_bytes_per_wg(c));
         return (uint32_t)std::max<uint64_t>(1, g);
     }
-    const uint32_t lds = SA_LDS_FIXED_BYTES + c->lds_dir_bytes;
+    const uint32_t lds = SA_LDS_FIXED_BYTES;
     uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>(c->wg_per_cu, (160u * 1024u) / lds));
     return (uint32_t)c->ncu * per_cu;
 }
@@ -268,6 +270,7 @@ int launch_work(sa_ctx* c, Work& w, bool timed) {
     P.codes_fo = (const uint8_t*)c->d_codes.p;
     P.len_fo = (const uint16_t*)c->d_len.p;
     P.codes_t = (const uint8_t*)c->d_codes_t.p;
+    P.codes_s = (const uint8_t*)c->d_codes_s.p;
     P.fi_sorted = (const uint32_t*)c->d_fi_sorted.p;
     P.len_sorted = (const uint16_t*)c->d_len_sorted.p;
     P.bucket_base = (const uint32_t*)c->d_bucket_base.p;
@@ -285,7 +288,6 @@ int launch_work(sa_ctx* c, Work& w, bool timed) {
     P.spill_rows = SA_LP;
     P.nseq = (uint32_t)c->nseq;
     P.gap = c->gap;
-    P.lds_dir_bytes = c->lds_dir_bytes;
     if (c->phase_timers) {
         if ((rc = c->d_phase.reserve((size_t)grid * 64))) return rc;
         SA_HIP_TRY(hipMemsetAsync(c->d_phase.p, 0, (size_t)grid * 64, c->compute));
@@ -298,7 +300,7 @@ int launch_work(sa_ctx* c, Work& w, bool timed) {
         sa_launch_long(w.schedule == SA_SCHEDULE_TRIANGULAR ? 0 : 1, &P, grid, SA_LDS_PROF_BYTES, c->compute);
     else
         sa_launch_peptide(w.schedule == SA_SCHEDULE_TRIANGULAR ? 0 : 1, &P, grid,
-                          SA_LDS_FIXED_BYTES + c->lds_dir_bytes, c->compute);
+                          SA_LDS_FIXED_BYTES, c->compute);
     SA_HIP_TRY(hipGetLastError());
     if (timed) SA_HIP_TRY(hipEventRecord(w.t1, c->compute));
     return SA_OK;
@@ -441,19 +443,15 @@ void sa_destroy(sa_ctx* c) {
     free_work(c->slots[0]); free_work(c->slots[1]); free_work(c->resident);
     c->d_codes.release(); c->d_len.release(); c->d_codes_t.release(); c->d_fi_sorted.release();
     c->d_len_sorted.release(); c->d_bucket_base.release(); c->d_cursor.release(); c->d_sprime.release();
-    c->d_spill.release(); c->d_bcol.release();
+    c->d_spill.release(); c->d_bcol.release(); c->d_codes_s.release();
     c->d_phase.release();
     if (c->compute) (void)hipStreamDestroy(c->compute);
     if (c->copy) (void)hipStreamDestroy(c->copy);
     delete c;
 }
 
-int sa_set_tuning(sa_ctx* c, uint32_t lds_dir_bytes, uint32_t tiles_per_item, uint32_t wg_per_cu) {
+int sa_set_tuning(sa_ctx* c, uint32_t tiles_per_item, uint32_t wg_per_cu) {
     if (!c) return SA_ERR_ARG;
-    if (lds_dir_bytes) {
-        if (lds_dir_bytes % 1024 || SA_LDS_FIXED_BYTES + lds_dir_bytes > 64 * 1024) return SA_ERR_ARG;
-        c->lds_dir_bytes = lds_dir_bytes;
-    }
     if (tiles_per_item) c->tiles_per_item = tiles_per_item;
     if (wg_per_cu) c->wg_per_cu = wg_per_cu;
     c->resident_ready = false;

@@ -71,6 +71,7 @@ typedef struct {
     const uint8_t* codes_fo;     /* [N][64] residue codes padded with SA_PAD_CODE, file order */
     const uint16_t* len_fo;      /* [N] */
     const uint8_t* codes_t;      /* [64 pos][npad] residue codes in bucket order, position-major */
+    const uint8_t* codes_s;      /* [npad][64] the same codes, one 64-byte slot per bucket-order slot */
     const uint32_t* fi_sorted;   /* [npad] file index of each bucket-order slot */
     const uint16_t* len_sorted;  /* [npad] */
     const uint32_t* bucket_base; /* [nb+1] first bucket-order slot of each bucket */
@@ -89,7 +90,6 @@ typedef struct {
     uint32_t spill_rows;
     uint32_t nseq;
     int32_t gap;
-    uint32_t lds_dir_bytes;      /* LDS bytes for direction rows (multiple of 1024) */
     unsigned long long* phase_cycles;  /* optional [grid][8] shader-cycle totals per phase, or NULL */
     /* long-sequence kernel only */
     uint32_t lslot;              /* bytes per file-order slot = rows of codes_t = row capacity (multiple of 64) */

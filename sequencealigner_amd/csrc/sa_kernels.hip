@@ -18,7 +18,9 @@
 // banks alternate between rows so no copies are needed.
 // Per cell two direction bits are produced from sign bits, (m-h)<0 and (up-h)<0,
 // and shifted into per-row bit planes with v_alignbit.  Rows of direction bits
-// go to LDS while they fit and to a per-workgroup global spill area after that.
+// go to a per-workgroup global area (8 or 16 bytes per lane and row, coalesced):
+// keeping them in LDS instead was measured to be worth 3 % and costs the LDS that
+// a third wave per SIMD needs.
 // The traceback walks one row per step: the run of LEFT moves inside a row is
 // a count-trailing-ones on (plane_nd & plane_nu); its output is one byte per row.
 //
@@ -32,55 +34,64 @@
 #include "sa_kernel_common.h"
 
 // ---------------------------------------------------------------- traceback
-// Bottom row first, four rows per chunk.  The loads of a chunk (direction words
-// from LDS or from the spill area, row residues) are issued two chunks ahead of
-// their use.  A row shifted ncols = 4*gend direction bits into each plane, so
-// column c sits at bit (ncols-1-c): plane A says "cell != diag + S'", plane B
-// "cell != up".  PT is uint32_t when ncols <= 32 (one word per plane) and
-// uint64_t otherwise.  Rows r >= split live in LDS (slot r - split), the rows
-// before them in the spill area.
+// Bottom row first, four rows per chunk.  The direction words of a chunk are
+// requested two chunks ahead of their use (global spill area, 8 or 16 bytes per
+// lane and row, coalesced).  A row shifted ncols = 4*gend direction bits into
+// each plane, so column c sits at bit (ncols-1-c): plane A says
+// "cell != diag + S'", plane B "cell != up".  PT is uint32_t when ncols <= 32
+// (one word per plane) and uint64_t otherwise.
+// Row residues (for counting matches): TRIANGULAR keeps the 64 residue codes of
+// the lane's second sequence in 16 registers (bw), ADJACENT reads them four at a
+// time from the sequence's slot.
 struct SaChunk {
     uint4 d[4];
-    int b[4];
+    uint32_t b4;    // ADJACENT: residues of the four rows
 };
+
+#define SA_WORD_CASE(K) case K: v = W[K]; break;
+__device__ __forceinline__ uint32_t pick_word(const uint32_t (&W)[16], const int k) {   // k is wave-uniform
+    uint32_t v = 0;
+    switch (k) {
+        SA_WORD_CASE(0) SA_WORD_CASE(1) SA_WORD_CASE(2) SA_WORD_CASE(3) SA_WORD_CASE(4) SA_WORD_CASE(5)
+        SA_WORD_CASE(6) SA_WORD_CASE(7) SA_WORD_CASE(8) SA_WORD_CASE(9) SA_WORD_CASE(10) SA_WORD_CASE(11)
+        SA_WORD_CASE(12) SA_WORD_CASE(13) SA_WORD_CASE(14) SA_WORD_CASE(15)
+        default: break;
+    }
+    return v;
+}
 
 template <int MODE, typename PT>
 __device__ __forceinline__ void traceback(const int lane, const int maxlen, const int lenq, const int lenp,
-                                          const int ncols, const int split, const uint32_t* __restrict__ dirs,
-                                          const uint32_t* __restrict__ spill, const uint8_t* __restrict__ brow,
-                                          const int bstep, const uint8_t* __restrict__ acol,
-                                          const uint64_t* __restrict__ emask, uint32_t* __restrict__ stage_rec,
-                                          int& matches_out, int& gaps_out) {
+                                          const int ncols, const uint32_t* __restrict__ spill,
+                                          const uint32_t (&bw)[16], const uint8_t* __restrict__ brow,
+                                          const uint8_t* __restrict__ acol, const uint64_t* __restrict__ emask,
+                                          uint32_t* __restrict__ stage_rec, int& matches_out, int& gaps_out) {
     constexpr bool WIDE = sizeof(PT) == 8;
     constexpr int PBITS = WIDE ? 63 : 31;
     int j = lenp, matches = 0, gaps = 0;
     const int nhi = ncols - 32;                              // WIDE: columns held by the second word
     const uint32_t himask = WIDE ? (uint32_t)((1ull << nhi) - 1) : 0;
 
-    // Nothing loaded here is used before process(): every request of a chunk (and
-    // of the two chunks after it) is in flight at once.  Row indices past the end
-    // of the longest sequence are clamped, so the requests need no guard.
+    // Nothing loaded here is used before process().  Row indices past the end of
+    // the longest sequence are clamped, so the requests need no guard.
     auto load_chunk = [&](int ch, SaChunk& ck) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int r = min(4 * ch + k, maxlen - 1);   // wave-uniform
-            ck.d[k] = make_uint4(0, 0, 0, 0);
-            if (r >= split) {
-                const int rr = r - split;
-                if (WIDE) ck.d[k] = *reinterpret_cast<const uint4*>(dirs + (rr * 64 + lane) * 4);
-                else { const uint2 t2 = *reinterpret_cast<const uint2*>(dirs + (rr * 64 + lane) * 2); ck.d[k].x = t2.x; ck.d[k].z = t2.y; }
-            } else {
-                if (WIDE) ck.d[k] = *reinterpret_cast<const uint4*>(spill + (r * 64 + lane) * 4);
-                else { const uint2 t2 = *reinterpret_cast<const uint2*>(spill + (r * 64 + lane) * 2); ck.d[k].x = t2.x; ck.d[k].z = t2.y; }
+            if (WIDE) ck.d[k] = *reinterpret_cast<const uint4*>(spill + (r * 64 + lane) * 4);
+            else {
+                const uint2 t2 = *reinterpret_cast<const uint2*>(spill + (r * 64 + lane) * 2);
+                ck.d[k] = make_uint4(t2.x, 0, t2.y, 0);
             }
-            ck.b[k] = brow[r * bstep];                   // residue codes are <= SA_PAD_CODE everywhere
         }
+        ck.b4 = (MODE == SA_MODE_ADJ) ? reinterpret_cast<const uint32_t*>(brow)[ch] : 0;
     };
 
     auto process = [&](int ch, const SaChunk& ck) {
+        const uint32_t b4 = (MODE == SA_MODE_TRI) ? pick_word(bw, ch) : ck.b4;
         uint64_t e[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) e[k] = (MODE == SA_MODE_TRI) ? emask[ck.b[k]] : 0;
+        for (int k = 0; k < 4; k++) e[k] = (MODE == SA_MODE_TRI) ? emask[(b4 >> (8 * k)) & 0xff] : 0;
         uint32_t packed = 0;
 #pragma unroll
         for (int k = 3; k >= 0; k--) {
@@ -107,7 +118,7 @@ __device__ __forceinline__ void traceback(const int lane, const int maxlen, cons
                 const int c = (j - 1) & 63;
                 int eq;
                 if (MODE == SA_MODE_TRI) eq = WIDE ? (int)((e[k] >> c) & 1) : (int)(((uint32_t)e[k] >> (c & 31)) & 1);
-                else eq = (t == 0 && (int)acol[c] == ck.b[k]) ? 1 : 0;
+                else eq = (t == 0 && (uint32_t)acol[c] == ((b4 >> (8 * k)) & 0xff)) ? 1 : 0;
                 matches += eq & dg;
                 j -= dg;
                 gaps += t;
@@ -145,7 +156,6 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_kernel(const Sa
     int32_t* const prof = reinterpret_cast<int32_t*>(smem);
     uint64_t* const emask = reinterpret_cast<uint64_t*>(smem + SA_LDS_PROF_BYTES);
     uint32_t* const stage = reinterpret_cast<uint32_t*>(smem + SA_LDS_PROF_BYTES + SA_LDS_EMASK_BYTES);
-    uint32_t* const dirs = reinterpret_cast<uint32_t*>(smem + SA_LDS_FIXED_BYTES);
     const int lane = threadIdx.x;
     uint32_t* const spill = P.spill + (size_t)blockIdx.x * P.spill_rows * 256;
     const uint32_t cpr = P.stride >> 4;   // 16-byte chunks per record
@@ -211,6 +221,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_kernel(const Sa
             const uint8_t* brow;          // row residue r of this lane at brow[r * bstep]
             int bstep;
             const uint8_t* acol = nullptr;   // ADJACENT: slot of sequence 1 (for match counting)
+            uint32_t sidx_l = 0;             // TRIANGULAR: bucket-order slot of this lane's second sequence
             if (MODE == SA_MODE_TRI) {
                 // 64 consecutive entries of p's valid list; the scan over buckets is wave-uniform
                 const uint32_t vbase = item.v0 + task * 64;
@@ -235,6 +246,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_kernel(const Sa
                 rel = fiq - item.p - 1;
                 brow = P.codes_t + sidx;
                 bstep = (int)P.npad;
+                sidx_l = sidx;
             } else {
                 active = (uint32_t)lane < item.count;
                 const uint32_t s1 = item.p + (active ? lane : 0);
@@ -258,9 +270,6 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_kernel(const Sa
                 }
             }
             const bool wide = gend > 8;                     // more than 32 columns: four plane words per row
-            const int wpr = wide ? 4 : 2;                   // dwords per direction row per lane
-            const int rows_lds = (int)(P.lds_dir_bytes / (uint32_t)(wpr * 256));
-            const int split = max(0, maxlen - rows_lds);    // rows >= split stay in LDS, earlier rows go to the spill area
 
             SA_PHASE(2);
             // -------------------------------------------------------------- fill
@@ -272,14 +281,8 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_kernel(const Sa
             // rows past the end of a sequence read padding (codes_t and the slots are 64 positions long)
             auto residue = [&](int r) -> int { return (int)brow[min(r, SA_LP - 1) * bstep]; };
             auto store_dirs = [&](int r) {
-                if (r >= split) {
-                    const int rr = r - split;
-                    if (wide) *reinterpret_cast<uint4*>(dirs + (rr * 64 + lane) * 4) = make_uint4(alo, ahi, blo, bhi);
-                    else *reinterpret_cast<uint2*>(dirs + (rr * 64 + lane) * 2) = make_uint2(alo, blo);
-                } else {
-                    if (wide) *reinterpret_cast<uint4*>(spill + (r * 64 + lane) * 4) = make_uint4(alo, ahi, blo, bhi);
-                    else *reinterpret_cast<uint2*>(spill + (r * 64 + lane) * 2) = make_uint2(alo, blo);
-                }
+                if (wide) *reinterpret_cast<uint4*>(spill + (r * 64 + lane) * 4) = make_uint4(alo, ahi, blo, bhi);
+                else *reinterpret_cast<uint2*>(spill + (r * 64 + lane) * 2) = make_uint2(alo, blo);
             };
 
             int b0 = residue(0), b1 = residue(1);
@@ -329,11 +332,24 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_kernel(const Sa
 
             SA_PHASE(3);
             int matches = 0, gaps = 0;
+            uint32_t bw[16];
+            if (MODE == SA_MODE_TRI) {
+                // the lane's second sequence, 64 residue codes in 16 registers
+                const uint4* src = reinterpret_cast<const uint4*>(P.codes_s + (size_t)sidx_l * SA_LP);
+#pragma unroll
+                for (int q4 = 0; q4 < 4; q4++) {
+                    const uint4 v = src[q4];
+                    bw[4 * q4 + 0] = v.x; bw[4 * q4 + 1] = v.y; bw[4 * q4 + 2] = v.z; bw[4 * q4 + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int q4 = 0; q4 < 16; q4++) bw[q4] = 0;
+            }
             if (wide)
-                traceback<MODE, uint64_t>(lane, maxlen, lenq, lenp, 4 * gend, split, dirs, spill, brow, bstep, acol, emask,
+                traceback<MODE, uint64_t>(lane, maxlen, lenq, lenp, 4 * gend, spill, bw, brow, acol, emask,
                                           stage + lane * SA_LDS_STAGE_DWORDS, matches, gaps);
             else
-                traceback<MODE, uint32_t>(lane, maxlen, lenq, lenp, 4 * gend, split, dirs, spill, brow, bstep, acol, emask,
+                traceback<MODE, uint32_t>(lane, maxlen, lenq, lenp, 4 * gend, spill, bw, brow, acol, emask,
                                           stage + lane * SA_LDS_STAGE_DWORDS, matches, gaps);
             SA_PHASE(4);
             stage[lane * SA_LDS_STAGE_DWORDS + 0] = (uint32_t)score;

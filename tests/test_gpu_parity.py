@@ -213,8 +213,8 @@ def test_tuning_knobs_do_not_change_results():
     al = sa.Aligner()
     al.upload(seqs)
     base = al.align(sa.TRIANGULAR)
-    for lds, tiles, wg in ((1024, 1, 2), (30 * 1024, 16, 4), (9 * 1024, 3, 8)):
-        al.set_tuning(lds_dir_bytes=lds, tiles_per_item=tiles, wg_per_cu=wg)
+    for tiles, wg in ((1, 2), (16, 4), (3, 12)):
+        al.set_tuning(tiles_per_item=tiles, wg_per_cu=wg)
         assert np.array_equal(al.align(sa.TRIANGULAR), base)
 
 
