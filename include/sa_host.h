@@ -52,6 +52,11 @@ typedef struct {
     uint64_t bytes_written;
     uint64_t chunks_done;
     double seconds;                   /* first byte parsed -> last byte written, set-up excluded (src/main.c:30,129) */
+    double seconds_ingest;            /* of which: map, parse, validate, encode */
+    double seconds_upload;            /*           sequences to the device(s) */
+    double seconds_gpu_wait;          /*           waiting for records (kernels + device-to-host copies not hidden) */
+    double seconds_format;            /*           expanding and formatting records */
+    double seconds_write;             /*           write() calls */
     char message[256];                /* error text when the return code is not 0 */
 } sa_run_report;
 

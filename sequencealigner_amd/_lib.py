@@ -76,6 +76,11 @@ class RunReport(C.Structure):
         ("bytes_written", C.c_uint64),
         ("chunks_done", C.c_uint64),
         ("seconds", C.c_double),
+        ("seconds_ingest", C.c_double),
+        ("seconds_upload", C.c_double),
+        ("seconds_gpu_wait", C.c_double),
+        ("seconds_format", C.c_double),
+        ("seconds_write", C.c_double),
         ("message", C.c_char * 256),
     ]
 

@@ -239,7 +239,8 @@ size_t spill_bytes_per_wg(const sa_ctx* c) {
 
 uint32_t grid_for(const sa_ctx* c) {
     if (is_long(c)) {
-        // 194 VGPRs: two waves per SIMD; the direction area of a workgroup is large, keep the total under 32 GiB
+        // two waves per SIMD (a third one spills registers inside the row loop: measured 1.8 vs 3.0 TCUPS);
+        // the direction area of a workgroup is large, keep the total under 32 GiB
         const uint64_t budget = 32ull << 30;
         uint64_t g = std::min<uint64_t>((uint64_t)c->ncu * 8, budget / spill_bytes_per_wg(c));
         return (uint32_t)std::max<uint64_t>(1, g);

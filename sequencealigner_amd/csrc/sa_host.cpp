@@ -341,6 +341,7 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
     }
 
     const double t0 = now_s();
+    double t_format = 0, t_write = 0, t_wait = 0;
     Table tab;
     rc = load_table(st, tab, err);
     if (rc) { cleanup(); if (out_fd >= 0) close(out_fd); return fail(rc); }
@@ -368,14 +369,17 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
             return fail(SA_ERR_ALPHABET);
         }
     }
+    rep->seconds_ingest = now_s() - t0;
     bool io_ok = true;
     if (out_fd >= 0) io_ok = write_all(out_fd, st->write_csv_header, strlen(st->write_csv_header));
 
     if (n >= 2) {
+        const double tu0 = now_s();
         for (int d = 0; d < ndev; d++) {
             rc = sa_upload(ctx[(size_t)d], codes.data(), offs.data(), lens.data(), n);
             if (rc) { cleanup(); if (out_fd >= 0) close(out_fd); return fail(rc); }
         }
+        rep->seconds_upload = now_s() - tu0;
         const int schedule = st->schedule;
         const uint64_t rows = sa_schedule_rows(ctx[0], schedule);
         rep->pairs = sa_pair_count(ctx[0], schedule, 0, rows);
@@ -416,7 +420,9 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
             sa_ctx* c = ctx[k % (size_t)ndev];
             const uint8_t* recs = nullptr;
             uint64_t first = 0, np = 0;
+            const double tw0 = now_s();
             if ((rc = sa_next(c, &recs, &first, &np))) break;
+            t_wait += now_s() - tw0;
             if (st->mode_write && np) {
                 std::atomic<int> bad(0);
                 auto work = [&](int t) {
@@ -448,15 +454,19 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
                     }
                     used[(size_t)t] = pos;
                 };
+                const double tf0 = now_s();
                 std::vector<std::thread> th;
                 for (int t = 1; t < nthreads; t++) th.emplace_back(work, t);
                 work(0);
                 for (auto& x : th) x.join();
+                t_format += now_s() - tf0;
+                const double tw1 = now_s();
                 if (bad.load()) { rc = SA_ERR_RECORD; }
                 for (int t = 0; t < nthreads && rc == SA_OK; t++) {
                     if (!write_all(out_fd, bufs[(size_t)t].data(), used[(size_t)t])) io_ok = false;
                     rep->bytes_written += used[(size_t)t];
                 }
+                t_write += now_s() - tw1;
             }
             if (rc == SA_OK) rc = sa_release(c);
             rep->chunks_done++;
@@ -465,6 +475,9 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
     rep->bytes_written += (out_fd >= 0) ? strlen(st->write_csv_header) : 0;
     const double t1 = now_s();
     rep->seconds = t1 - t0;
+    rep->seconds_gpu_wait = t_wait;
+    rep->seconds_format = t_format;
+    rep->seconds_write = t_write;
     if (out_fd >= 0) close(out_fd);
     cleanup();
     if (rc) return fail(rc);

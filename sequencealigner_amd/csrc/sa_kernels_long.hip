@@ -18,8 +18,8 @@
 // waiting for one, and no cross-lane exchange is needed in the fill.
 #include "sa_kernel_common.h"
 
-template <int MODE>
-__global__ void __launch_bounds__(64, 2) sa_long_kernel(const SaPepParams P) {
+template <int MODE, int WAVES_PER_SIMD>
+__global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_kernel(const SaPepParams P) {
     extern __shared__ __align__(16) uint8_t smem[];
     int32_t* const prof = reinterpret_cast<int32_t*>(smem);
     const int lane = threadIdx.x;
@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(64, 2) sa_long_kernel(const SaPepParams P) {
 
 extern "C" void sa_launch_long(int mode, const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream) {
     if (mode == SA_MODE_TRI)
-        hipLaunchKernelGGL(sa_long_kernel<SA_MODE_TRI>, dim3(grid), dim3(64), lds_bytes, stream, *p);
+        hipLaunchKernelGGL((sa_long_kernel<SA_MODE_TRI, 2>), dim3(grid), dim3(64), lds_bytes, stream, *p);
     else
-        hipLaunchKernelGGL(sa_long_kernel<SA_MODE_ADJ>, dim3(grid), dim3(64), lds_bytes, stream, *p);
+        hipLaunchKernelGGL((sa_long_kernel<SA_MODE_ADJ, 2>), dim3(grid), dim3(64), lds_bytes, stream, *p);
 }

@@ -24,7 +24,7 @@ t = time.time(); synth.make_mega('tests/golden/avpdb.csv', '/tmp/mega.csv'); pri
 for thr in (16,):
     rep = sa.run_csv('/tmp/mega.csv', '/tmp/mega_out.csv', sa.ADJACENT, format_threads=thr)
     h = sha('/tmp/mega_out.csv'); same = h == '667f3524a9ba31243de55c075165b336010ffeaf76600b39540b54f5dd085f18'
-    print('mega adjacent: pairs', rep.pairs, 'bytes', rep.bytes_written, 'seconds %.3f' % rep.seconds, 'Mpairs/s %.2f' % (rep.pairs/rep.seconds/1e6), 'sha ok:', same, flush=True); ok &= same
+    print('mega adjacent: pairs', rep.pairs, 'bytes', rep.bytes_written, 'seconds %.3f' % rep.seconds, 'Mpairs/s %.2f' % (rep.pairs/rep.seconds/1e6), 'sha ok:', same, 'ingest %.3f upload %.3f wait %.3f format %.3f write %.3f' % (rep.seconds_ingest, rep.seconds_upload, rep.seconds_gpu_wait, rep.seconds_format, rep.seconds_write), flush=True); ok &= same
 rep = sa.run_csv('/tmp/mega.csv', None, sa.ADJACENT)
 print('mega adjacent no-write: seconds %.3f' % rep.seconds, 'Mpairs/s %.2f' % (rep.pairs/rep.seconds/1e6), flush=True)
 sys.exit(0 if ok else 1)
