@@ -15,8 +15,8 @@
 #include "../../include/sa_hip.h"
 #include "sa_device.h"
 
-extern "C" void sa_launch_peptide(int mode, const SaPepParams* p, unsigned grid, unsigned lds_bytes,
-                                  hipStream_t stream);
+extern "C" void sa_launch_peptide(int mode, int waves_per_simd, const SaPepParams* p, unsigned grid,
+                                  unsigned lds_bytes, hipStream_t stream);
 extern "C" void sa_launch_long(int mode, const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream);
 
 namespace {
@@ -300,7 +300,7 @@ int launch_work(sa_ctx* c, Work& w, bool timed) {
     if (is_long(c))
         sa_launch_long(w.schedule == SA_SCHEDULE_TRIANGULAR ? 0 : 1, &P, grid, SA_LDS_PROF_BYTES, c->compute);
     else
-        sa_launch_peptide(w.schedule == SA_SCHEDULE_TRIANGULAR ? 0 : 1, &P, grid,
+        sa_launch_peptide(w.schedule == SA_SCHEDULE_TRIANGULAR ? 0 : 1, c->wg_per_cu > 8 ? 3 : 2, &P, grid,
                           SA_LDS_FIXED_BYTES, c->compute);
     SA_HIP_TRY(hipGetLastError());
     if (timed) SA_HIP_TRY(hipEventRecord(w.t1, c->compute));

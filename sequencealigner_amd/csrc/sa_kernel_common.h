@@ -61,16 +61,18 @@ __device__ __forceinline__ int wave_min(int v) {
     if (gend == (G) + 1) return;
 
 // One DP row of the TRIANGULAR kernel: IN = previous row, OUT = this row,
-// columns 0 .. 4*gend-1 (gend is wave-uniform).  sc0: in = scores of columns
-// 0..3 for this row, out = the same for the next row (requested at the top of
-// the row, used one row later).
+// columns 0 .. 4*gend-1 (gend is wave-uniform).  sc_in = scores of columns 0..3
+// for this row; sc_out receives the same for the next row (requested at the top
+// of the row, used one row later).  The caller alternates two variables between
+// rows so that no register copies are needed at the loop edge.
 __device__ __forceinline__ void fill_row_tri(const int (&IN)[SA_LP], int (&OUT)[SA_LP], const int gend,
                                              const int diag0, const int left0,
                                              const int32_t* __restrict__ row_base,
-                                             const int32_t* __restrict__ next_row_base, int4& sc0,
+                                             const int32_t* __restrict__ next_row_base, const int4& sc_in,
+                                             int4& sc_out,
                                              uint32_t& alo, uint32_t& ahi, uint32_t& blo, uint32_t& bhi) {
-    int4 scE = sc0, scO;
-    sc0 = *reinterpret_cast<const int4*>(next_row_base);
+    int4 scE = sc_in, scO;
+    sc_out = *reinterpret_cast<const int4*>(next_row_base);
     SA_GROUP_TRI(0, scE, scO, alo, blo)
     SA_GROUP_TRI(1, scO, scE, alo, blo)
     SA_GROUP_TRI(2, scE, scO, alo, blo)

@@ -287,17 +287,19 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_kernel(const Sa
 
             int b0 = residue(0), b1 = residue(1);
             if (MODE == SA_MODE_TRI) {
+                // one variable for both rows: a second one would remove four copies per row but costs
+                // four VGPRs, and at the 168-register budget of three waves per SIMD that means spills
                 int4 sc0 = *reinterpret_cast<const int4*>(prof + b0 * SA_PROF_STRIDE);
                 for (int r = 0; r < maxlen; r += 2) {
                     // residues two rows ahead: their latency is covered by two rows of arithmetic
                     const int b2 = residue(r + 2), b3 = residue(r + 3);
                     if (r < lenq) {
-                        fill_row_tri(R, Q, gend, 0, 0, prof + b0 * SA_PROF_STRIDE, prof + b1 * SA_PROF_STRIDE, sc0,
+                        fill_row_tri(R, Q, gend, 0, 0, prof + b0 * SA_PROF_STRIDE, prof + b1 * SA_PROF_STRIDE, sc0, sc0,
                                      alo, ahi, blo, bhi);
                         store_dirs(r);
                     }
                     if (r + 1 < lenq) {
-                        fill_row_tri(Q, R, gend, 0, 0, prof + b1 * SA_PROF_STRIDE, prof + b2 * SA_PROF_STRIDE, sc0,
+                        fill_row_tri(Q, R, gend, 0, 0, prof + b1 * SA_PROF_STRIDE, prof + b2 * SA_PROF_STRIDE, sc0, sc0,
                                      alo, ahi, blo, bhi);
                         store_dirs(r + 1);
                     }
@@ -377,10 +379,14 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_kernel(const Sa
 #undef SA_PHASE
 }
 
-extern "C" void sa_launch_peptide(int mode, const SaPepParams* p, unsigned grid, unsigned lds_bytes,
-                                  hipStream_t stream) {
-    if (mode == SA_MODE_TRI)
+// waves_per_simd selects the register budget of the TRIANGULAR kernel: 3 (168 VGPRs, some
+// spills) or 2 (up to 256 VGPRs)
+extern "C" void sa_launch_peptide(int mode, int waves_per_simd, const SaPepParams* p, unsigned grid,
+                                  unsigned lds_bytes, hipStream_t stream) {
+    if (mode == SA_MODE_TRI && waves_per_simd >= 3)
         hipLaunchKernelGGL((sa_peptide_kernel<SA_MODE_TRI, 3>), dim3(grid), dim3(64), lds_bytes, stream, *p);
+    else if (mode == SA_MODE_TRI)
+        hipLaunchKernelGGL((sa_peptide_kernel<SA_MODE_TRI, 2>), dim3(grid), dim3(64), lds_bytes, stream, *p);
     else
         hipLaunchKernelGGL((sa_peptide_kernel<SA_MODE_ADJ, 2>), dim3(grid), dim3(64), lds_bytes, stream, *p);
 }

@@ -145,14 +145,14 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_kernel(const SaPep
                 int b0 = residue(0), b1 = residue(1);
                 int l0 = border(0), l1 = border(1);
                 int dprev = 0;                                   // left border value of the previous row = diag of column 0
-                int4 sc0 = make_int4(0, 0, 0, 0);
+                int4 sc0 = make_int4(0, 0, 0, 0), sc1 = sc0;
                 if (MODE == SA_MODE_TRI) sc0 = *reinterpret_cast<const int4*>(prof + b0 * SA_PROF_STRIDE);
                 for (int r = 0; r < maxlen; r += 2) {
                     const int b2 = residue(r + 2), b3 = residue(r + 3);
                     const int l2 = border(r + 2), l3 = border(r + 3);
                     if (r < lenq) {
                         if (MODE == SA_MODE_TRI)
-                            fill_row_tri(R, Q, gend, dprev, l0, prof + b0 * SA_PROF_STRIDE, prof + b1 * SA_PROF_STRIDE, sc0,
+                            fill_row_tri(R, Q, gend, dprev, l0, prof + b0 * SA_PROF_STRIDE, prof + b1 * SA_PROF_STRIDE, sc0, sc1,
                                          alo, ahi, blo, bhi);
                         else
                             fill_row_adj(R, Q, gend, dprev, l0, prof + (b0 < 20 ? b0 : 0) * 32, a4, alo, ahi, blo, bhi);
@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_kernel(const SaPep
                     }
                     if (r + 1 < lenq) {
                         if (MODE == SA_MODE_TRI)
-                            fill_row_tri(Q, R, gend, l0, l1, prof + b1 * SA_PROF_STRIDE, prof + b2 * SA_PROF_STRIDE, sc0,
+                            fill_row_tri(Q, R, gend, l0, l1, prof + b1 * SA_PROF_STRIDE, prof + b2 * SA_PROF_STRIDE, sc1, sc0,
                                          alo, ahi, blo, bhi);
                         else
                             fill_row_adj(Q, R, gend, l0, l1, prof + (b1 < 20 ? b1 : 0) * 32, a4, alo, ahi, blo, bhi);
