@@ -31,6 +31,8 @@
 // second sequences: 64 consecutive entries of p's valid list (bucket order).
 // ADJACENT mode: lane l aligns file rows (k+l, k+l+1); scores are looked up in
 // an LDS copy of S'.
+#include <type_traits>
+
 #include "sa_kernel_common.h"
 
 // ---------------------------------------------------------------- traceback
@@ -38,8 +40,8 @@
 // requested two chunks ahead of their use (global spill area, 8 or 16 bytes per
 // lane and row, coalesced).  A row shifted ncols = 4*gend direction bits into
 // each plane, so column c sits at bit (ncols-1-c): plane A says
-// "cell != diag + S'", plane B "cell != up".  PT is uint32_t when ncols <= 32
-// (one word per plane) and uint64_t otherwise.
+// "cell != diag + S'", plane B "cell != up".  A row is stored in W = ceil(ncols/16)
+// dwords per lane: {A|B<<16}, {A,B}, {Alo,Blo,Ahi|Bhi<<16} or {Alo,Ahi,Blo,Bhi}.
 // Row residues (for counting matches): TRIANGULAR keeps the 64 residue codes of
 // the lane's second sequence in 16 registers (bw), ADJACENT reads them four at a
 // time from the sequence's slot.
@@ -60,17 +62,18 @@ __device__ __forceinline__ uint32_t pick_word(const uint32_t (&W)[16], const int
     return v;
 }
 
-template <int MODE, typename PT>
+template <int MODE, int W>
 __device__ __forceinline__ void traceback(const int lane, const int maxlen, const int lenq, const int lenp,
                                           const int ncols, const uint32_t* __restrict__ spill,
                                           const uint32_t (&bw)[16], const uint8_t* __restrict__ brow,
                                           const uint8_t* __restrict__ acol, const uint64_t* __restrict__ emask,
                                           uint32_t* __restrict__ stage_rec, int& matches_out, int& gaps_out) {
-    constexpr bool WIDE = sizeof(PT) == 8;
+    constexpr bool WIDE = W > 2;
+    using PT = typename std::conditional<WIDE, uint64_t, uint32_t>::type;
     constexpr int PBITS = WIDE ? 63 : 31;
     int j = lenp, matches = 0, gaps = 0;
     const int nhi = ncols - 32;                              // WIDE: columns held by the second word
-    const uint32_t himask = WIDE ? (uint32_t)((1ull << nhi) - 1) : 0;
+    const uint32_t himask = WIDE ? (uint32_t)((1ull << nhi) - 1) : 0;   // nhi <= 16 when W == 3
 
     // Nothing loaded here is used before process().  Row indices past the end of
     // the longest sequence are clamped, so the requests need no guard.
@@ -78,10 +81,18 @@ __device__ __forceinline__ void traceback(const int lane, const int maxlen, cons
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int r = min(4 * ch + k, maxlen - 1);   // wave-uniform
-            if (WIDE) ck.d[k] = *reinterpret_cast<const uint4*>(spill + (r * 64 + lane) * 4);
-            else {
-                const uint2 t2 = *reinterpret_cast<const uint2*>(spill + (r * 64 + lane) * 2);
+            // ck.d[k] = {Alo, Ahi, Blo, Bhi} whatever the stored form
+            const uint32_t* src = spill + (r * 64 + lane) * W;
+            if (W == 4) ck.d[k] = *reinterpret_cast<const uint4*>(src);
+            else if (W == 3) {
+                const uint32_t w0 = src[0], w1 = src[1], w2 = src[2];
+                ck.d[k] = make_uint4(w0, w2, w1, w2 >> 16);
+            } else if (W == 2) {
+                const uint2 t2 = *reinterpret_cast<const uint2*>(src);
                 ck.d[k] = make_uint4(t2.x, 0, t2.y, 0);
+            } else {
+                const uint32_t w0 = src[0];
+                ck.d[k] = make_uint4(w0 & 0xffffu, 0, w0 >> 16, 0);
             }
         }
         ck.b4 = (MODE == SA_MODE_ADJ) ? reinterpret_cast<const uint32_t*>(brow)[ch] : 0;
@@ -269,7 +280,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_kernel(const Sa
                     a4[4 * w + 3] = (v >> 24) << 2;
                 }
             }
-            const bool wide = gend > 8;                     // more than 32 columns: four plane words per row
+            const int wpr = (gend + 3) >> 2;                // dwords per direction row and lane: ceil(columns / 16)
 
             SA_PHASE(2);
             // -------------------------------------------------------------- fill
@@ -281,8 +292,11 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_kernel(const Sa
             // rows past the end of a sequence read padding (codes_t and the slots are 64 positions long)
             auto residue = [&](int r) -> int { return (int)brow[min(r, SA_LP - 1) * bstep]; };
             auto store_dirs = [&](int r) {
-                if (wide) *reinterpret_cast<uint4*>(spill + (r * 64 + lane) * 4) = make_uint4(alo, ahi, blo, bhi);
-                else *reinterpret_cast<uint2*>(spill + (r * 64 + lane) * 2) = make_uint2(alo, blo);
+                uint32_t* dst = spill + (r * 64 + lane) * wpr;
+                if (wpr == 4) *reinterpret_cast<uint4*>(dst) = make_uint4(alo, ahi, blo, bhi);
+                else if (wpr == 3) { dst[0] = alo; dst[1] = blo; dst[2] = (ahi & 0xffffu) | (bhi << 16); }
+                else if (wpr == 2) *reinterpret_cast<uint2*>(dst) = make_uint2(alo, blo);
+                else dst[0] = (alo & 0xffffu) | (blo << 16);
             };
 
             int b0 = residue(0), b1 = residue(1);
@@ -347,12 +361,14 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_kernel(const Sa
 #pragma unroll
                 for (int q4 = 0; q4 < 16; q4++) bw[q4] = 0;
             }
-            if (wide)
-                traceback<MODE, uint64_t>(lane, maxlen, lenq, lenp, 4 * gend, spill, bw, brow, acol, emask,
-                                          stage + lane * SA_LDS_STAGE_DWORDS, matches, gaps);
-            else
-                traceback<MODE, uint32_t>(lane, maxlen, lenq, lenp, 4 * gend, spill, bw, brow, acol, emask,
-                                          stage + lane * SA_LDS_STAGE_DWORDS, matches, gaps);
+#define SA_TRACEBACK(WW)                                                                                   \
+    traceback<MODE, WW>(lane, maxlen, lenq, lenp, 4 * gend, spill, bw, brow, acol, emask,                   \
+                        stage + lane * SA_LDS_STAGE_DWORDS, matches, gaps)
+            if (wpr == 4) SA_TRACEBACK(4);
+            else if (wpr == 3) SA_TRACEBACK(3);
+            else if (wpr == 2) SA_TRACEBACK(2);
+            else SA_TRACEBACK(1);
+#undef SA_TRACEBACK
             SA_PHASE(4);
             stage[lane * SA_LDS_STAGE_DWORDS + 0] = (uint32_t)score;
             stage[lane * SA_LDS_STAGE_DWORDS + 1] = (uint32_t)matches | ((uint32_t)gaps << 16);
