@@ -11,8 +11,13 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Wall -Wno-unused-functi
 all: lib oracle
 
 MAIN    := sequencealigner_amd/sa_main
+TOOLS   := sequencealigner_amd/sa_tune sequencealigner_amd/sa_dataset
 
-lib: $(LIB) $(MAIN)
+lib: $(LIB) $(MAIN) $(TOOLS)
+sequencealigner_amd/sa_tune: $(CSRC)/sa_tune.cpp $(LIB)
+	$(HIPCC) -O2 -std=c++17 -Wall -o $@ $(CSRC)/sa_tune.cpp -Lsequencealigner_amd -lsa_hip -Wl,-rpath,'$$ORIGIN'
+sequencealigner_amd/sa_dataset: $(CSRC)/sa_dataset.c
+	gcc -O2 -Wall -Wextra -o $@ $(CSRC)/sa_dataset.c
 $(MAIN): $(CSRC)/sa_main.cpp $(LIB)
 	$(HIPCC) -O2 -std=c++17 -Wall -o $@ $(CSRC)/sa_main.cpp -Lsequencealigner_amd -lsa_hip -Wl,-rpath,'$$ORIGIN'
 $(LIB): $(CSRC)/sa_kernel_common.h $(CSRC)/sa_kernels.hip $(CSRC)/sa_kernels_long.hip $(CSRC)/sa_api.cpp $(CSRC)/sa_host.cpp $(CSRC)/sa_device.h include/sa_hip.h include/sa_host.h
@@ -22,5 +27,5 @@ oracle:
 	$(MAKE) -C oracle all
 
 clean:
-	rm -f $(LIB) $(MAIN)
+	rm -f $(LIB) $(MAIN) $(TOOLS)
 	$(MAKE) -C oracle clean

@@ -36,13 +36,13 @@ typedef struct {
     char write_csv_align_fmt[128];    /* WRITE_CSV_ALIGN_FMT: two %s */
     int32_t mode_write;               /* MODE_WRITE: 0 = align only (include/user.h:65, src/main.c:111-116) */
     int32_t similarity_analysis;      /* SIMILARITY_ANALYSIS */
-    uint32_t batch_size;              /* BATCH_SIZE: rows per batch; one GPU submission covers 64 batches unless pairs_per_submit is set */
+    uint32_t batch_size;              /* BATCH_SIZE: rows per batch; one GPU submission covers 4 batches unless pairs_per_submit is set */
     /* settings the reference does not have */
     int32_t schedule;                 /* SA_SCHEDULE_ADJACENT (the reference's) or SA_SCHEDULE_TRIANGULAR */
     int32_t num_devices;              /* GPUs to use, chunks are dealt to them in turn */
     int32_t devices[8];
     int32_t format_threads;           /* host threads that expand and format records; 0 = min(16, cores) */
-    uint64_t pairs_per_submit;        /* 0 = batch_size * 64 */
+    uint64_t pairs_per_submit;        /* 0 = batch_size * 4 */
 } sa_settings;
 
 typedef struct {

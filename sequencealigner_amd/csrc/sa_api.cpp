@@ -14,9 +14,12 @@
 
 #include "../../include/sa_hip.h"
 #include "sa_device.h"
+#include "sa_parallel.h"
 
 extern "C" void sa_launch_peptide(int mode, int waves_per_simd, const SaPepParams* p, unsigned grid,
                                   unsigned lds_bytes, hipStream_t stream);
+extern "C" void sa_launch_pack_slots(const uint8_t* codes, const uint64_t* offs, const uint32_t* lens, uint64_t nseq,
+                                     uint64_t nslots, uint32_t lslot, uint8_t* slots, uint16_t* len16, hipStream_t stream);
 extern "C" void sa_launch_long(int mode, const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream);
 
 namespace {
@@ -464,12 +467,29 @@ int sa_upload(sa_ctx* c, const uint8_t* codes, const uint64_t* offs, const uint3
     if (nseq == 0 || nseq >= 0xFFFFFFF0ull) return SA_ERR_ARG;
     if (c->inflight) return SA_ERR_STATE;
     if (c->device != SA_DEVICE_NONE) SA_HIP_TRY(hipSetDevice(c->device));
+    // validation and the length range, on the host threads
+    struct Part { uint32_t lmin = 0xFFFFFFFFu, lmax = 0; uint64_t total = 0; int err = SA_OK; };
+    std::vector<Part> part(sa_host_threads());
+    const uint32_t max_len = c->max_len;
+    sa_parallel_for(nseq, 1 << 16, [&](uint64_t lo, uint64_t hi, unsigned t) {
+        Part q;
+        for (uint64_t s = lo; s < hi && q.err == SA_OK; s++) {
+            const uint32_t l = lens[s];
+            if (l == 0 || l > max_len) { q.err = SA_ERR_LENGTH; break; }
+            q.lmin = std::min(q.lmin, l); q.lmax = std::max(q.lmax, l);
+            q.total = std::max(q.total, offs[s] + l);
+            const uint8_t* src = codes + offs[s];
+            uint32_t worst = 0;
+            for (uint32_t i = 0; i < l; i++) worst = std::max<uint32_t>(worst, src[i]);
+            if (worst >= 20) q.err = SA_ERR_ALPHABET;
+        }
+        part[t] = q;
+    });
     uint32_t lmin = 0xFFFFFFFFu, lmax = 0;
-    for (uint64_t s = 0; s < nseq; s++) {
-        if (lens[s] == 0 || lens[s] > c->max_len) return SA_ERR_LENGTH;
-        lmin = std::min(lmin, lens[s]); lmax = std::max(lmax, lens[s]);
-        for (uint32_t i = 0; i < lens[s]; i++)
-            if (codes[offs[s] + i] >= 20) return SA_ERR_ALPHABET;
+    uint64_t total = 0;
+    for (const Part& q : part) {
+        if (q.err) return q.err;
+        lmin = std::min(lmin, q.lmin); lmax = std::max(lmax, q.lmax); total = std::max(total, q.total);
     }
     c->nseq = nseq;
     c->min_seq = lmin;
@@ -483,26 +503,41 @@ int sa_upload(sa_ctx* c, const uint8_t* codes, const uint64_t* offs, const uint3
     c->resident_ready = false;
     c->tri_ready = false;
 
-    // file-order slots padded with SA_PAD_CODE (plus two spare slots)
-    std::vector<uint8_t> slots((size_t)(nseq + 2) * lslot, SA_PAD_CODE);
-    c->len.assign(nseq, 0);
-    c->offs_host.assign(offs, offs + nseq);
-    uint64_t total = 0;
-    for (uint64_t s = 0; s < nseq; s++) total = std::max(total, offs[s] + lens[s]);
-    c->codes_host.assign(codes, codes + total);
-    for (uint64_t s = 0; s < nseq; s++) {
-        c->len[s] = (uint16_t)lens[s];
-        memcpy(&slots[(size_t)s * lslot], codes + offs[s], lens[s]);
-    }
-    c->len_suffix.assign(nseq + 1, 0);
+    // host mirrors: lengths, suffix sums of the lengths, the caller's arrays
+    c->len.resize(nseq);
+    c->offs_host.resize(nseq);
+    c->codes_host.resize(total);
+    sa_parallel_for(nseq, 1 << 16, [&](uint64_t lo, uint64_t hi, unsigned) {
+        for (uint64_t s = lo; s < hi; s++) { c->len[s] = (uint16_t)lens[s]; c->offs_host[s] = offs[s]; }
+    });
+    sa_parallel_for(total, 1 << 22, [&](uint64_t lo, uint64_t hi, unsigned) { memcpy(c->codes_host.data() + lo, codes + lo, hi - lo); });
+    c->len_suffix.resize(nseq + 1);
+    c->len_suffix[nseq] = 0;
     for (uint64_t s = nseq; s-- > 0;) c->len_suffix[s] = c->len_suffix[s + 1] + c->len[s];
     if (c->device == SA_DEVICE_NONE) return SA_OK;
+
+    // device: the compact arrays go up as they are; a kernel spreads them into the file-order
+    // slots padded with SA_PAD_CODE (plus two spare slots) and the 16-bit length table
     int rc;
-    if ((rc = c->d_codes.reserve(slots.size()))) return rc;
-    if ((rc = c->d_len.reserve((nseq + 64) * 2))) return rc;
-    SA_HIP_TRY(hipMemcpy(c->d_codes.p, slots.data(), slots.size(), hipMemcpyHostToDevice));
-    SA_HIP_TRY(hipMemset(c->d_len.p, 0, (nseq + 64) * 2));
-    SA_HIP_TRY(hipMemcpy(c->d_len.p, c->len.data(), nseq * 2, hipMemcpyHostToDevice));
+    const uint64_t nslots = nseq + 2;
+    const size_t raw_bytes = (total + 64 + 15) & ~(size_t)15;   // slack: the kernel may read a few bytes past a sequence
+    DevBuf stage;
+    if ((rc = stage.reserve(raw_bytes + nseq * 8 + nseq * 4))) return rc;
+    uint8_t* d_raw = (uint8_t*)stage.p;
+    uint64_t* d_offs = (uint64_t*)(d_raw + raw_bytes);
+    uint32_t* d_lens = (uint32_t*)(d_raw + raw_bytes + nseq * 8);
+    if ((rc = c->d_codes.reserve((size_t)nslots * lslot)) || (rc = c->d_len.reserve((nseq + 64) * 2))) { stage.release(); return rc; }
+    hipError_t e = hipMemcpyAsync(d_raw, codes, total, hipMemcpyHostToDevice, c->compute);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_offs, offs, nseq * 8, hipMemcpyHostToDevice, c->compute);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_lens, lens, nseq * 4, hipMemcpyHostToDevice, c->compute);
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_len.p, 0, (nseq + 64) * 2, c->compute);
+    if (e == hipSuccess) {
+        sa_launch_pack_slots(d_raw, d_offs, d_lens, nseq, nslots, lslot, (uint8_t*)c->d_codes.p, (uint16_t*)c->d_len.p, c->compute);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->compute);
+    stage.release();
+    if (e != hipSuccess) return hip_code(e);
     return SA_OK;
 }
 

@@ -21,6 +21,7 @@
 
 #include "../../include/sa_hip.h"
 #include "../../include/sa_host.h"
+#include "sa_parallel.h"
 
 namespace {
 
@@ -62,28 +63,53 @@ int load_table(const sa_settings* st, Table& t, std::string& err) {
     t.data = (char*)mmap(nullptr, t.size, PROT_READ, MAP_PRIVATE, t.fd, 0);
     if (t.data == MAP_FAILED) { err = "cannot map input file"; return SA_ERR_ARG; }
     madvise(t.data, t.size, MADV_SEQUENTIAL);
-    const char* p = t.data;
-    const char* end = t.data + t.size;
-    while (p < end && *p != '\n') p++;
-    if (p < end) p++;
-    t.rows.reserve(t.size / 24 + 16);
-    while (p < end && *p) {
-        while (p < end && (*p == ' ' || *p == '\r' || *p == '\n')) p++;
-        if (p >= end || !*p) break;
-        Row r = {nullptr, 0, "", 0};
-        uint32_t col = 0;
-        bool have_other = false;
-        while (p < end && *p && *p != '\n' && *p != '\r') {
-            const char* f = p;
-            while (p < end && *p && *p != ',' && *p != '\n' && *p != '\r') p++;
-            if (col == st->read_csv_seq_pos) { r.seq = f; r.len = (uint32_t)(p - f); }
-            else if (!have_other) { r.other = f; r.other_len = (uint32_t)(p - f); have_other = true; }
-            if (p < end && *p == ',') { p++; col++; }
+    const char* const end = t.data + t.size;
+    const char* body = t.data;
+    while (body < end && *body != '\n') body++;
+    if (body < end) body++;
+    // A NUL ends the table (include/csv.h:150); lines are then parsed in slices that start after a newline.
+    const char* stop = (const char*)memchr(body, 0, (size_t)(end - body));
+    if (!stop) stop = end;
+    const uint32_t seq_pos = st->read_csv_seq_pos;
+    auto parse = [seq_pos](const char* p, const char* lim, std::vector<Row>& rows) {
+        rows.reserve((size_t)(lim - p) / 24 + 16);
+        while (p < lim) {
+            while (p < lim && (*p == ' ' || *p == '\r' || *p == '\n')) p++;
+            if (p >= lim) break;
+            Row r = {nullptr, 0, "", 0};
+            uint32_t col = 0;
+            bool have_other = false;
+            while (p < lim && *p != '\n' && *p != '\r') {
+                const char* f = p;
+                while (p < lim && *p != ',' && *p != '\n' && *p != '\r') p++;
+                if (col == seq_pos) { r.seq = f; r.len = (uint32_t)(p - f); }
+                else if (!have_other) { r.other = f; r.other_len = (uint32_t)(p - f); have_other = true; }
+                if (p < lim && *p == ',') { p++; col++; }
+            }
+            if (!r.seq) { r.seq = p; r.len = 0; }
+            rows.push_back(r);
+            while (p < lim && (*p == '\n' || *p == '\r')) p++;
         }
-        if (!r.seq) { r.seq = p; r.len = 0; }
-        t.rows.push_back(r);
-        while (p < end && (*p == '\n' || *p == '\r')) p++;
-    }
+    };
+    const uint64_t bytes = (uint64_t)(stop - body);
+    std::vector<std::vector<Row>> part(sa_host_threads());
+    const unsigned T = sa_parallel_for(bytes, 1 << 22, [&](uint64_t lo, uint64_t hi, unsigned th) {
+        // a slice owns the lines that begin in it: move both ends forward to the next line start
+        const char* a = body + lo;
+        const char* b = body + hi;
+        if (lo) { while (a < stop && a[-1] != '\n' && a[-1] != '\r') a++; }
+        if (hi < bytes) { while (b < stop && b[-1] != '\n' && b[-1] != '\r') b++; }
+        parse(a, b, part[th]);
+    });
+    if (T == 1) { t.rows.swap(part[0]); return SA_OK; }
+    size_t n = 0;
+    std::vector<size_t> base(T + 1, 0);
+    for (unsigned k = 0; k < T; k++) { n += part[k].size(); base[k + 1] = n; }
+    t.rows.resize(n);
+    sa_parallel_for(T, 1, [&](uint64_t lo, uint64_t hi, unsigned) {
+        for (uint64_t k = lo; k < hi; k++)
+            if (!part[k].empty()) memcpy(&t.rows[base[k]], part[k].data(), part[k].size() * sizeof(Row));
+    });
     return SA_OK;
 }
 
@@ -191,6 +217,15 @@ bool write_all(int fd, const char* p, size_t n) {
         ssize_t w = write(fd, p, n);
         if (w < 0) { if (errno == EINTR) continue; return false; }
         p += w; n -= (size_t)w;
+    }
+    return true;
+}
+
+bool pwrite_all(int fd, const char* p, size_t n, uint64_t off) {
+    while (n) {
+        ssize_t w = pwrite(fd, p, n, (off_t)off);
+        if (w < 0) { if (errno == EINTR) continue; return false; }
+        p += w; n -= (size_t)w; off += (uint64_t)w;
     }
     return true;
 }
@@ -362,12 +397,19 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
         offs[s] = total; lens[s] = r.len; total += r.len;
     }
     std::vector<uint8_t> codes(total + 1);
-    for (uint64_t s = 0; s < n; s++) {
-        if (sa_encode(tab.rows[s].seq, lens[s], codes.data() + offs[s]) != SA_OK) {
-            err = "row " + std::to_string(s + 2) + ": residue outside " SA_ALPHABET;
-            cleanup(); if (out_fd >= 0) close(out_fd);
-            return fail(SA_ERR_ALPHABET);
-        }
+    std::atomic<uint64_t> bad_row(UINT64_MAX);
+    sa_parallel_for(n, 1 << 15, [&](uint64_t lo, uint64_t hi, unsigned) {
+        for (uint64_t s = lo; s < hi; s++)
+            if (sa_encode(tab.rows[s].seq, lens[s], codes.data() + offs[s]) != SA_OK) {
+                uint64_t seen = bad_row.load();
+                while (s < seen && !bad_row.compare_exchange_weak(seen, s)) {}
+                return;
+            }
+    });
+    if (bad_row.load() != UINT64_MAX) {
+        err = "row " + std::to_string(bad_row.load() + 2) + ": residue outside " SA_ALPHABET;
+        cleanup(); if (out_fd >= 0) close(out_fd);
+        return fail(SA_ERR_ALPHABET);
     }
     rep->seconds_ingest = now_s() - t0;
     bool io_ok = true;
@@ -388,7 +430,7 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
         const uint32_t row_bytes = sa_record_row_bytes(ctx[0]);
 
         // chunks of whole schedule rows; chunk k goes to device k % ndev, results are consumed in chunk order
-        uint64_t cap = st->pairs_per_submit ? st->pairs_per_submit : (uint64_t)st->batch_size * 64;
+        uint64_t cap = st->pairs_per_submit ? st->pairs_per_submit : (uint64_t)st->batch_size * 4;   // 262144 at the default BATCH_SIZE: the best of the tuner's sweep with writing on
         if (cap < 1) cap = 1;
         std::vector<Chunk> chunks;
         for (uint64_t r0 = 0; r0 < rows;) {
@@ -399,8 +441,14 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
             r0 = r1;
         }
         int nthreads = st->format_threads > 0 ? st->format_threads : (int)std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
-        std::vector<std::vector<char>> bufs((size_t)nthreads);
-        std::vector<size_t> used((size_t)nthreads);
+        // two sets of format buffers: one is written to the file by a writer thread while the other is filled
+        std::vector<std::vector<char>> bufset[2] = {std::vector<std::vector<char>>((size_t)nthreads), std::vector<std::vector<char>>((size_t)nthreads)};
+        std::vector<size_t> usedset[2] = {std::vector<size_t>((size_t)nthreads), std::vector<size_t>((size_t)nthreads)};
+        std::thread writer[2];
+        std::atomic<bool> write_failed(false);
+        std::atomic<uint64_t> written(0);
+        uint64_t file_off = strlen(st->write_csv_header);       // where the next chunk's text starts in the file
+        int cur_set = 0;
         const size_t row_bound = 4 * (size_t)st->max_seq_len + 2 * 256 + L.part[0].size() + L.part[1].size() + L.part[2].size() + 64;
 
         size_t next_submit = 0;
@@ -424,6 +472,11 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
             if ((rc = sa_next(c, &recs, &first, &np))) break;
             t_wait += now_s() - tw0;
             if (st->mode_write && np) {
+                const double tj0 = now_s();
+                if (writer[cur_set].joinable()) writer[cur_set].join();     // this set's previous contents are on disk
+                t_write += now_s() - tj0;
+                std::vector<std::vector<char>>& bufs = bufset[cur_set];
+                std::vector<size_t>& used = usedset[cur_set];
                 std::atomic<int> bad(0);
                 auto work = [&](int t) {
                     const uint64_t lo = np * (uint64_t)t / (uint64_t)nthreads, hi = np * (uint64_t)(t + 1) / (uint64_t)nthreads;
@@ -460,17 +513,35 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
                 work(0);
                 for (auto& x : th) x.join();
                 t_format += now_s() - tf0;
-                const double tw1 = now_s();
                 if (bad.load()) { rc = SA_ERR_RECORD; }
-                for (int t = 0; t < nthreads && rc == SA_OK; t++) {
-                    if (!write_all(out_fd, bufs[(size_t)t].data(), used[(size_t)t])) io_ok = false;
-                    rep->bytes_written += used[(size_t)t];
+                if (rc == SA_OK) {
+                    // chunks are written in order: the previous writer must be done before this one starts
+                    const double tj1 = now_s();
+                    if (writer[cur_set ^ 1].joinable()) writer[cur_set ^ 1].join();
+                    t_write += now_s() - tj1;
+                    // every format slice goes to its own place in the file, all slices at once
+                    const uint64_t chunk_off = file_off;
+                    for (int t = 0; t < nthreads; t++) file_off += used[(size_t)t];
+                    writer[cur_set] = std::thread([&bufs, &used, &write_failed, &written, out_fd, nthreads, chunk_off]() {
+                        std::vector<uint64_t> at((size_t)nthreads + 1, chunk_off);
+                        for (int t = 0; t < nthreads; t++) at[(size_t)t + 1] = at[(size_t)t] + used[(size_t)t];
+                        sa_parallel_for((uint64_t)nthreads, 1, [&](uint64_t lo, uint64_t hi, unsigned) {
+                            for (uint64_t t = lo; t < hi; t++)
+                                if (!pwrite_all(out_fd, bufs[t].data(), used[t], at[t])) write_failed.store(true);
+                        });
+                        written.fetch_add(at[(size_t)nthreads] - chunk_off);
+                    });
+                    cur_set ^= 1;
                 }
-                t_write += now_s() - tw1;
             }
             if (rc == SA_OK) rc = sa_release(c);
             rep->chunks_done++;
         }
+        const double tj2 = now_s();
+        for (auto& w : writer) if (w.joinable()) w.join();
+        t_write += now_s() - tj2;
+        rep->bytes_written += written.load();
+        if (write_failed.load()) io_ok = false;
     }
     rep->bytes_written += (out_fd >= 0) ? strlen(st->write_csv_header) : 0;
     const double t1 = now_s();

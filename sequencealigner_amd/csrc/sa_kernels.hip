@@ -397,6 +397,45 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_kernel(const Sa
 
 // waves_per_simd selects the register budget of the TRIANGULAR kernel: 3 (168 VGPRs, some
 // spills) or 2 (up to 256 VGPRs)
+// File-order slots from the compact upload: slot s holds the codes of sequence s followed by
+// SA_PAD_CODE up to lslot bytes; slots at and past nseq are all padding.  One thread per 16 bytes.
+__global__ __launch_bounds__(256) void sa_pack_slots_kernel(const uint8_t* __restrict__ codes, const uint64_t* __restrict__ offs,
+                                                            const uint32_t* __restrict__ lens, uint64_t nseq, uint64_t nslots,
+                                                            uint32_t lslot, uint8_t* __restrict__ slots, uint16_t* __restrict__ len16) {
+    const uint32_t per = lslot >> 4;
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t s = t / per;
+    if (s >= nslots) return;
+    const uint32_t ch = (uint32_t)(t - s * per);
+    uint32_t len = 0;
+    const uint8_t* src = codes;
+    if (s < nseq) {
+        len = lens[s];
+        src = codes + offs[s];
+        if (ch == 0) len16[s] = (uint16_t)len;
+    }
+    uint32_t w[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const uint32_t i = ch * 16 + k * 4 + b;
+            const uint32_t code = i < len ? src[i] : (uint32_t)SA_PAD_CODE;
+            v |= code << (8 * b);
+        }
+        w[k] = v;
+    }
+    *(uint4*)(slots + s * lslot + ch * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+extern "C" void sa_launch_pack_slots(const uint8_t* codes, const uint64_t* offs, const uint32_t* lens, uint64_t nseq,
+                                     uint64_t nslots, uint32_t lslot, uint8_t* slots, uint16_t* len16, hipStream_t stream) {
+    const uint64_t threads = nslots * (lslot >> 4);
+    const unsigned grid = (unsigned)((threads + 255) / 256);
+    hipLaunchKernelGGL(sa_pack_slots_kernel, dim3(grid), dim3(256), 0, stream, codes, offs, lens, nseq, nslots, lslot, slots, len16);
+}
+
 extern "C" void sa_launch_peptide(int mode, int waves_per_simd, const SaPepParams* p, unsigned grid,
                                   unsigned lds_bytes, hipStream_t stream) {
     if (mode == SA_MODE_TRI && waves_per_simd >= 3)

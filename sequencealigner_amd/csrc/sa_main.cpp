@@ -49,9 +49,11 @@ int main(int argc, char** argv) {
     if (rc != SA_OK) { fprintf(stderr, "error %d: %s\n", rc, rep.message); return 1; }
     printf("Alignment time: %f seconds\n", rep.seconds);
     printf("{\"rows\": %llu, \"pairs\": %llu, \"cells\": %llu, \"bytes_written\": %llu, \"seconds\": %.6f, "
-           "\"gcups\": %.3f, \"pairs_per_s\": %.1f, \"devices\": %d}\n",
+           "\"gcups\": %.3f, \"pairs_per_s\": %.1f, \"devices\": %d, \"seconds_ingest\": %.4f, \"seconds_upload\": %.4f, "
+           "\"seconds_gpu_wait\": %.4f, \"seconds_format\": %.4f, \"seconds_write\": %.4f}\n",
            (unsigned long long)rep.rows, (unsigned long long)rep.pairs, (unsigned long long)rep.cells,
            (unsigned long long)rep.bytes_written, rep.seconds, rep.seconds > 0 ? rep.cells / rep.seconds / 1e9 : 0.0,
-           rep.seconds > 0 ? rep.pairs / rep.seconds : 0.0, st.num_devices);
+           rep.seconds > 0 ? rep.pairs / rep.seconds : 0.0, st.num_devices, rep.seconds_ingest, rep.seconds_upload,
+           rep.seconds_gpu_wait, rep.seconds_format, rep.seconds_write);
     return 0;
 }

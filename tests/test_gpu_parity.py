@@ -12,7 +12,7 @@ import pytest
 import oracle_lib
 import sequencealigner_amd as sa
 from conftest import sha256_file
-from sequencealigner_amd import synth
+from sequencealigner_amd import _lib, synth
 
 pytestmark = pytest.mark.gpu
 ALPHABET = "ARNDCQEGHILKMFPSTWYV"
@@ -244,3 +244,30 @@ def test_full_size_peptide_set_sampled_against_oracle():
     gaps = blk[:, 6].astype(np.int64) | (blk[:, 7].astype(np.int64) << 8)
     matches = blk[:, 4].astype(np.int64) | (blk[:, 5].astype(np.int64) << 8)
     assert (matches >= 0).all() and (gaps <= 50).all() and (matches <= 50).all()
+
+
+@pytest.mark.gpu
+def test_large_adjacent_file_with_threaded_ingest_equals_oracle(tmp_path):
+    """Enough rows that the CSV parser, the encoder, the upload and the writer all run on several
+    host threads and several submissions (a slice boundary may fall anywhere in a line)."""
+    seqs, labels = synth.generate(300000, 1, 40, 77)
+    src = tmp_path / "big.csv"
+    synth.write_csv(str(src), seqs, labels)
+    ours, theirs = tmp_path / "ours.csv", tmp_path / "oracle.csv"
+    sa.run_csv(str(src), str(ours), sa.ADJACENT, pairs_per_submit=50000)
+    oracle_lib.run_file(str(src), str(theirs), 0, threads=8)
+    assert ours.read_bytes() == theirs.read_bytes()
+
+
+@pytest.mark.gpu
+def test_tuner_prints_its_two_tables(tmp_path):
+    import subprocess
+    seqs, labels = synth.generate(5000, 6, 50, 3)
+    src = tmp_path / "in.csv"
+    synth.write_csv(str(src), seqs, labels)
+    tool = os.path.join(os.path.dirname(_lib.lib_path()), "sa_tune")
+    out = subprocess.run([tool, "--input", str(src), "--kernel-rows", "2000"], capture_output=True, text=True, timeout=110)
+    assert out.returncode == 0, out.stderr
+    assert "Pairs per submission\tTime (s)\tPairs/s" in out.stdout
+    assert "Tiles per item\tWaves per CU\tKernel (ms)\tGCUPS" in out.stdout
+    assert out.stdout.count("\n") >= 6 + 1 + 2 + 10

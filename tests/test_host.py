@@ -256,3 +256,36 @@ def test_settings_validation_rules():
     st = sa.default_settings()
     st.write_csv_header = b"too,few,columns\n"
     assert sa.validate_settings(st)[0] != 0
+
+
+# ---- data set tool (C): same files as the Python generator, mega layout of scripts/create_mega_dataset.py:121-167
+
+DATASET_TOOL = os.path.join(os.path.dirname(_lib.lib_path()), "sa_dataset")
+
+
+def test_c_dataset_tool_equals_python_generator(tmp_path):
+    import subprocess
+    c_out, p_out = tmp_path / "c.csv", tmp_path / "p.csv"
+    subprocess.run([DATASET_TOOL, "synth", "700", "1", "64", "42", str(c_out)], check=True)
+    seqs, labels = synth.generate(700, 1, 64, 42)
+    synth.write_csv(str(p_out), seqs, labels)
+    assert c_out.read_bytes() == p_out.read_bytes()
+
+
+def test_c_dataset_tool_mega_layout(tmp_path):
+    import subprocess
+    src = tmp_path / "in.csv"
+    src.write_bytes(b"h1,h2\nAAA,0\nCCC,1\nDDD,0\n")
+    out = tmp_path / "mega.csv"
+    subprocess.run([DATASET_TOOL, "mega", str(src), str(out), "2"], check=True)
+    body = b"AAA,0\nCCC,1\nDDD,0\n"
+    rev = b"DDD,0\nCCC,1\nAAA,0\n"
+    assert out.read_bytes() == b"h1,h2\n" + (body + rev) * 2
+    p_out = tmp_path / "pmega.csv"
+    synth.make_mega(str(src), str(p_out), 2)
+    assert p_out.read_bytes() == out.read_bytes()
+
+
+def test_c_dataset_tool_usage_error():
+    import subprocess
+    assert subprocess.run([DATASET_TOOL, "nothing"], capture_output=True).returncode == 2
