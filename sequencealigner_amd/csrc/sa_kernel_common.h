@@ -121,6 +121,100 @@ __device__ __forceinline__ void fill_row_adj(const int (&IN)[SA_LP], int (&OUT)[
     }
 }
 
+// ---- tagged cells (peptide kernel) ------------------------------------------
+// Values are kept as 4*D plus a 2-bit tag, and the tag of the winning operand
+// of the max3 tells the traceback where the cell came from:
+//   diagonal operand  4*(Dd + S') + 3     (bank value 4*Dd + 1 plus table entry 4*S' + 2)
+//   upper operand     4*Du + 1            (bank value as it is)
+//   left operand      4*Dl + 0            (tag cleared)
+// On equal D the larger tag wins, which is the reference's preference DIAG, UP,
+// LEFT (include/seqalign.h:73-105).  Bit 0 of a tag says "not LEFT", bit 1 "DIAG",
+// so a count-leading-zeros over a row's tags gives the length of a run of LEFT
+// moves (clz / 2) and what ends it (clz odd: UP, even: DIAG).
+// Per cell: add, max3, alignbit (the two tag bits go into the row's direction
+// word), and (left operand of the next column), or (bank value for the next row)
+// -- five instructions, two of them on the slow issue path, against six with
+// three slow ones for the sign-bit scheme.
+#define SA_TAG_LEFT 0
+#define SA_TAG_UP 1
+#define SA_TAG_DIAG 3
+#define SA_TAG_TABLE(sprime) (4 * (sprime) + 2)     /* table entry for a substitution score S' */
+
+#define SA_CELL_TAG(IN, OUT, C, T, ACC)                                          \
+    {                                                                            \
+        const int diag_ = ((C) == 0) ? diag0 : IN[((C) == 0) ? 0 : (C) - 1];     \
+        const int m_ = diag_ + (T);                                              \
+        const int h_ = max3i(m_, IN[C], zl);                                     \
+        ACC = __builtin_amdgcn_alignbit((uint32_t)h_, ACC, 2);                   \
+        zl = h_ & ~3;                                                            \
+        OUT[C] = zl | 1;                                                         \
+    }
+
+#define SA_GROUP_TAG(G, CUR, NXT, ACC)                                             \
+    NXT = *reinterpret_cast<const int4*>(row_base + 4 * ((G) + 1));                \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+    SA_CELL_TAG(IN, OUT, 4 * (G) + 0, CUR.x, ACC)                                  \
+    SA_CELL_TAG(IN, OUT, 4 * (G) + 1, CUR.y, ACC)                                  \
+    SA_CELL_TAG(IN, OUT, 4 * (G) + 2, CUR.z, ACC)                                  \
+    SA_CELL_TAG(IN, OUT, 4 * (G) + 3, CUR.w, ACC)                                  \
+    if (gend == (G) + 1) return;
+
+// One row of tagged cells, TRIANGULAR operands (see fill_row_tri for the protocol of
+// row_base / next_row_base / sc_in / sc_out).  IN and OUT hold 4*D + 1; diag0 is the
+// border value in that form (1 on the matrix border), left0 the border value with
+// the tag cleared (0).  e[q] receives the tags of columns 16q .. 16q+15, newest on
+// top: after k cells column 16q + i sits at bits 32 - 2(k - i).
+__device__ __forceinline__ void fill_row_tri_tag(const int (&IN)[SA_LP], int (&OUT)[SA_LP], const int gend,
+                                                 const int diag0, const int left0,
+                                                 const int32_t* __restrict__ row_base,
+                                                 const int32_t* __restrict__ next_row_base, const int4& sc_in,
+                                                 int4& sc_out, uint32_t& e0, uint32_t& e1, uint32_t& e2,
+                                                 uint32_t& e3) {
+    int4 scE = sc_in, scO;
+    int zl = left0;
+    sc_out = *reinterpret_cast<const int4*>(next_row_base);
+    SA_GROUP_TAG(0, scE, scO, e0)
+    SA_GROUP_TAG(1, scO, scE, e0)
+    SA_GROUP_TAG(2, scE, scO, e0)
+    SA_GROUP_TAG(3, scO, scE, e0)
+    SA_GROUP_TAG(4, scE, scO, e1)
+    SA_GROUP_TAG(5, scO, scE, e1)
+    SA_GROUP_TAG(6, scE, scO, e1)
+    SA_GROUP_TAG(7, scO, scE, e1)
+    SA_GROUP_TAG(8, scE, scO, e2)
+    SA_GROUP_TAG(9, scO, scE, e2)
+    SA_GROUP_TAG(10, scE, scO, e2)
+    SA_GROUP_TAG(11, scO, scE, e2)
+    SA_GROUP_TAG(12, scE, scO, e3)
+    SA_GROUP_TAG(13, scO, scE, e3)
+    SA_GROUP_TAG(14, scE, scO, e3)
+    SA_GROUP_TAG(15, scO, scE, e3)
+}
+
+// The same row with ADJACENT operands: table entries SA_TAG_TABLE(S') from an LDS copy, row
+// selected by the row residue, entry by the column residue (a4 = 4 * residue code).
+__device__ __forceinline__ void fill_row_adj_tag(const int (&IN)[SA_LP], int (&OUT)[SA_LP], const int gend,
+                                                 const int diag0, const int left0,
+                                                 const int32_t* __restrict__ row_base, const int (&a4)[SA_LP],
+                                                 uint32_t& e0, uint32_t& e1, uint32_t& e2, uint32_t& e3) {
+    const char* rb = reinterpret_cast<const char*>(row_base);
+    int zl = left0;
+#pragma unroll
+    for (int g = 0; g < SA_LP / 4; g++) {
+        if (g < gend) {   // wave-uniform
+            const int s0 = *reinterpret_cast<const int32_t*>(rb + a4[4 * g + 0]);
+            const int s1 = *reinterpret_cast<const int32_t*>(rb + a4[4 * g + 1]);
+            const int s2 = *reinterpret_cast<const int32_t*>(rb + a4[4 * g + 2]);
+            const int s3 = *reinterpret_cast<const int32_t*>(rb + a4[4 * g + 3]);
+            uint32_t& acc = g < 4 ? e0 : g < 8 ? e1 : g < 12 ? e2 : e3;
+            SA_CELL_TAG(IN, OUT, 4 * g + 0, s0, acc)
+            SA_CELL_TAG(IN, OUT, 4 * g + 1, s1, acc)
+            SA_CELL_TAG(IN, OUT, 4 * g + 2, s2, acc)
+            SA_CELL_TAG(IN, OUT, 4 * g + 3, s3, acc)
+        }
+    }
+}
+
 // value of register column `col` (wave-uniform) of a row bank
 #define SA_PICK_CASE(C) case C: v = BANK[C]; break;
 __device__ __forceinline__ int pick_column(const int (&BANK)[SA_LP], const int col) {

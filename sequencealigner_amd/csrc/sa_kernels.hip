@@ -16,13 +16,16 @@
 // The DP row lives in VGPRs (up to 64 columns, processed four at a time; a row
 // stops after the last group that holds a residue of sequence 1).  Two register
 // banks alternate between rows so no copies are needed.
-// Per cell two direction bits are produced from sign bits, (m-h)<0 and (up-h)<0,
-// and shifted into per-row bit planes with v_alignbit.  Rows of direction bits
-// go to a per-workgroup global area (8 or 16 bytes per lane and row, coalesced):
-// keeping them in LDS instead was measured to be worth 3 % and costs the LDS that
-// a third wave per SIMD needs.
-// The traceback walks one row per step: the run of LEFT moves inside a row is
-// a count-trailing-ones on (plane_nd & plane_nu); its output is one byte per row.
+// Registers hold 4*D plus a 2-bit tag; the tag of the operand that wins the max3
+// (3 diagonal, 1 up, 0 left) is the cell's direction, so ties resolve the way the
+// reference's traceback resolves them, and v_alignbit moves the two bits into the
+// row's direction words: five instructions per cell (sa_kernel_common.h).
+// Rows of direction words go to a per-workgroup global area (4 to 16 bytes per lane
+// and row, coalesced): keeping them in LDS instead was measured to be worth 3 % and
+// costs the LDS that a third wave per SIMD needs.
+// The traceback walks one row per step: the run of LEFT moves inside a row is a
+// count-leading-zeros on the "tag != 0" flags below the current column; its output
+// is one byte per row.
 //
 // TRIANGULAR mode: all lanes of a wave share sequence 1 (file row p); its
 // substitution scores are expanded once into an LDS "query profile"
@@ -37,11 +40,9 @@
 
 // ---------------------------------------------------------------- traceback
 // Bottom row first, four rows per chunk.  The direction words of a chunk are
-// requested two chunks ahead of their use (global spill area, 8 or 16 bytes per
-// lane and row, coalesced).  A row shifted ncols = 4*gend direction bits into
-// each plane, so column c sits at bit (ncols-1-c): plane A says
-// "cell != diag + S'", plane B "cell != up".  A row is stored in W = ceil(ncols/16)
-// dwords per lane: {A|B<<16}, {A,B}, {Alo,Blo,Ahi|Bhi<<16} or {Alo,Ahi,Blo,Bhi}.
+// requested two chunks ahead of their use (global spill area, coalesced).  A row
+// is W = ceil(ncols/16) dwords per lane; the tag of column c is bits 2(c%16),
+// 2(c%16)+1 of dword c/16 (0 LEFT, 1 UP, 3 DIAG).
 // Row residues (for counting matches): TRIANGULAR keeps the 64 residue codes of
 // the lane's second sequence in 16 registers (bw), ADJACENT reads them four at a
 // time from the sequence's slot.
@@ -62,18 +63,24 @@ __device__ __forceinline__ uint32_t pick_word(const uint32_t (&W)[16], const int
     return v;
 }
 
+// dword i (per lane) of a direction row: 0 below the row, the last dword above it
+template <int W>
+__device__ __forceinline__ uint32_t dir_word(const uint4& d, const int i) {
+    uint32_t v = d.x;
+    if (i < 0) v = 0;
+    if (W == 2) { if (i >= 1) v = d.y; }
+    if (W == 3) { if (i == 1) v = d.y; if (i >= 2) v = d.z; }
+    if (W == 4) { if (i == 1) v = d.y; if (i == 2) v = d.z; if (i >= 3) v = d.w; }
+    return v;
+}
+
 template <int MODE, int W>
 __device__ __forceinline__ void traceback(const int lane, const int maxlen, const int lenq, const int lenp,
-                                          const int ncols, const uint32_t* __restrict__ spill,
+                                          const uint32_t* __restrict__ spill,
                                           const uint32_t (&bw)[16], const uint8_t* __restrict__ brow,
                                           const uint8_t* __restrict__ acol, const uint64_t* __restrict__ emask,
                                           uint32_t* __restrict__ stage_rec, int& matches_out, int& gaps_out) {
-    constexpr bool WIDE = W > 2;
-    using PT = typename std::conditional<WIDE, uint64_t, uint32_t>::type;
-    constexpr int PBITS = WIDE ? 63 : 31;
     int j = lenp, matches = 0, gaps = 0;
-    const int nhi = ncols - 32;                              // WIDE: columns held by the second word
-    const uint32_t himask = WIDE ? (uint32_t)((1ull << nhi) - 1) : 0;   // nhi <= 16 when W == 3
 
     // Nothing loaded here is used before process().  Row indices past the end of
     // the longest sequence are clamped, so the requests need no guard.
@@ -81,19 +88,13 @@ __device__ __forceinline__ void traceback(const int lane, const int maxlen, cons
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int r = min(4 * ch + k, maxlen - 1);   // wave-uniform
-            // ck.d[k] = {Alo, Ahi, Blo, Bhi} whatever the stored form
             const uint32_t* src = spill + (r * 64 + lane) * W;
             if (W == 4) ck.d[k] = *reinterpret_cast<const uint4*>(src);
-            else if (W == 3) {
-                const uint32_t w0 = src[0], w1 = src[1], w2 = src[2];
-                ck.d[k] = make_uint4(w0, w2, w1, w2 >> 16);
-            } else if (W == 2) {
+            else if (W == 3) ck.d[k] = make_uint4(src[0], src[1], src[2], 0);
+            else if (W == 2) {
                 const uint2 t2 = *reinterpret_cast<const uint2*>(src);
-                ck.d[k] = make_uint4(t2.x, 0, t2.y, 0);
-            } else {
-                const uint32_t w0 = src[0];
-                ck.d[k] = make_uint4(w0 & 0xffffu, 0, w0 >> 16, 0);
-            }
+                ck.d[k] = make_uint4(t2.x, t2.y, 0, 0);
+            } else ck.d[k] = make_uint4(src[0], 0, 0, 0);
         }
         ck.b4 = (MODE == SA_MODE_ADJ) ? reinterpret_cast<const uint32_t*>(brow)[ch] : 0;
     };
@@ -108,28 +109,44 @@ __device__ __forceinline__ void traceback(const int lane, const int maxlen, cons
         for (int k = 3; k >= 0; k--) {
             const int r = 4 * ch + k;
             if (r < lenq) {
-                PT A, B;
-                if (WIDE) {
-                    A = (PT)(((uint64_t)ck.d[k].x << nhi) | (ck.d[k].y & himask));
-                    B = (PT)(((uint64_t)ck.d[k].z << nhi) | (ck.d[k].w & himask));
+                // The tags of columns j-1, j-2, ... are moved to the top of a window, most recent
+                // column first; L = leading zeros = 2 * (run of LEFT) + (1 if an UP ends it, 0 if a
+                // DIAG does).  Branch-free per lane: with j == 0 the window is meaningless, the run
+                // is cut to 0 and the move is UP (left border).
+                int L;
+                if (W == 1) {
+                    const uint32_t x = ck.d[k].x << ((32 - 2 * j) & 31);
+                    L = x ? __builtin_clz(x) : 32;
+                } else if (W == 2) {
+                    const uint64_t v = ((uint64_t)ck.d[k].y << 32) | ck.d[k].x;
+                    const uint64_t x = v << ((64 - 2 * j) & 63);
+                    L = x ? __builtin_clzll(x) : 64;
                 } else {
-                    A = (PT)ck.d[k].x;
-                    B = (PT)ck.d[k].z;
+                    // 32-bit window over dwords j/16 and j/16 - 1; a run of 16 or more LEFT moves that
+                    // has not reached column 0 goes on in the dwords below (rare)
+                    const int wi = j >> 4, sh = (2 * j) & 31;
+                    const uint32_t x = __builtin_amdgcn_alignbit(dir_word<W>(ck.d[k], wi), dir_word<W>(ck.d[k], wi - 1), sh);
+                    L = x ? __builtin_clz(x) : 32;
+                    bool more = (x == 0) && (j > 16);
+                    int below = 1;
+                    while (__any(more)) {
+                        if (more) {
+                            const uint32_t y = __builtin_amdgcn_alignbit(dir_word<W>(ck.d[k], wi - below),
+                                                                         dir_word<W>(ck.d[k], wi - below - 1), sh);
+                            L = 32 * below + (y ? __builtin_clz(y) : 32);
+                            below++;
+                            more = (y == 0) && (j > 16 * below);
+                        }
+                    }
                 }
-                // branch-free: with j == 0 the shifted values are meaningless and overridden
-                const PT x = (PT) ~((A & B) >> ((ncols - j) & PBITS));    // zero bit = first column that is not LEFT
-                int run;
-                if (WIDE) run = x ? __builtin_ctzll((uint64_t)x) : 64;
-                else run = x ? __builtin_ctz((uint32_t)x) : 32;
-                run = min(run, j);
+                const int run = min(L >> 1, j);
                 j -= run;
-                const int bit = (int)((A >> ((ncols - j) & PBITS)) & 1);
-                const int t = (j > 0) ? bit : 1;                          // 0 = DIAG, 1 = UP (left border: UP)
+                const int t = (j > 0) ? (L & 1) : 1;                       // 0 = DIAG, 1 = UP (left border: UP)
+                const int c1 = (j - 1) & 63;
                 const int dg = t ^ 1;
-                const int c = (j - 1) & 63;
                 int eq;
-                if (MODE == SA_MODE_TRI) eq = WIDE ? (int)((e[k] >> c) & 1) : (int)(((uint32_t)e[k] >> (c & 31)) & 1);
-                else eq = (t == 0 && (uint32_t)acol[c] == ((b4 >> (8 * k)) & 0xff)) ? 1 : 0;
+                if (MODE == SA_MODE_TRI) eq = (W > 2) ? (int)((e[k] >> c1) & 1) : (int)(((uint32_t)e[k] >> (c1 & 31)) & 1);
+                else eq = (t == 0 && (uint32_t)acol[c1] == ((b4 >> (8 * k)) & 0xff)) ? 1 : 0;
                 matches += eq & dg;
                 j -= dg;
                 gaps += t;
@@ -177,10 +194,10 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_kernel(const Sa
 #define SA_PHASE(k) do { if (timed) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tph[k] += t_ - tmark; tmark = t_; } } while (0)
 
     if (MODE == SA_MODE_ADJ) {
-        // LDS copy of S' laid out [b][a] so that a row residue selects a 128-byte row
+        // LDS copy of SA_TAG_TABLE(S') laid out [b][a] so that a row residue selects a 128-byte row
         for (int e = lane; e < 20 * 32; e += 64) {
             const int b = e >> 5, a = e & 31;
-            prof[e] = (a <= 20) ? P.sprime[a * SA_SPRIME_STRIDE + b] : 0;
+            prof[e] = SA_TAG_TABLE((a <= 20) ? P.sprime[a * SA_SPRIME_STRIDE + b] : 0);
         }
         __syncthreads();
     }
@@ -203,8 +220,8 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_kernel(const Sa
             const int a = P.codes_fo[(size_t)p * SA_LP + lane];
             __syncthreads();   // previous item's readers are done with prof/emask
 #pragma unroll
-            for (int b = 0; b < 20; b++) prof[b * SA_PROF_STRIDE + lane] = P.sprime[a * SA_SPRIME_STRIDE + b];
-            prof[20 * SA_PROF_STRIDE + lane] = 0;
+            for (int b = 0; b < 20; b++) prof[b * SA_PROF_STRIDE + lane] = SA_TAG_TABLE(P.sprime[a * SA_SPRIME_STRIDE + b]);
+            prof[20 * SA_PROF_STRIDE + lane] = SA_TAG_TABLE(0);
 #pragma unroll
             for (int b = 0; b < 20; b++) {
                 const uint64_t mk = __ballot(a == b);
@@ -286,17 +303,19 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_kernel(const Sa
             // -------------------------------------------------------------- fill
             int R[SA_LP], Q[SA_LP];
 #pragma unroll
-            for (int c = 0; c < SA_LP; c++) { R[c] = 0; Q[c] = 0; }
-            uint32_t alo = 0, ahi = 0, blo = 0, bhi = 0;
+            for (int c = 0; c < SA_LP; c++) { R[c] = 1; Q[c] = 1; }     // border row: 4*0 + 1
+            uint32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;
 
             // rows past the end of a sequence read padding (codes_t and the slots are 64 positions long)
             auto residue = [&](int r) -> int { return (int)brow[min(r, SA_LP - 1) * bstep]; };
+            // the last dword of a row took ncols - 16*(wpr-1) cells: move its first column down to bit 0
+            const int lsh = 32 - 2 * (4 * gend - 16 * (wpr - 1));
             auto store_dirs = [&](int r) {
                 uint32_t* dst = spill + (r * 64 + lane) * wpr;
-                if (wpr == 4) *reinterpret_cast<uint4*>(dst) = make_uint4(alo, ahi, blo, bhi);
-                else if (wpr == 3) { dst[0] = alo; dst[1] = blo; dst[2] = (ahi & 0xffffu) | (bhi << 16); }
-                else if (wpr == 2) *reinterpret_cast<uint2*>(dst) = make_uint2(alo, blo);
-                else dst[0] = (alo & 0xffffu) | (blo << 16);
+                if (wpr == 4) *reinterpret_cast<uint4*>(dst) = make_uint4(e0, e1, e2, e3 >> lsh);
+                else if (wpr == 3) { dst[0] = e0; dst[1] = e1; dst[2] = e2 >> lsh; }
+                else if (wpr == 2) *reinterpret_cast<uint2*>(dst) = make_uint2(e0, e1 >> lsh);
+                else dst[0] = e0 >> lsh;
             };
 
             int b0 = residue(0), b1 = residue(1);
@@ -308,13 +327,13 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_kernel(const Sa
                     // residues two rows ahead: their latency is covered by two rows of arithmetic
                     const int b2 = residue(r + 2), b3 = residue(r + 3);
                     if (r < lenq) {
-                        fill_row_tri(R, Q, gend, 0, 0, prof + b0 * SA_PROF_STRIDE, prof + b1 * SA_PROF_STRIDE, sc0, sc0,
-                                     alo, ahi, blo, bhi);
+                        fill_row_tri_tag(R, Q, gend, 1, 0, prof + b0 * SA_PROF_STRIDE, prof + b1 * SA_PROF_STRIDE, sc0, sc0,
+                                         e0, e1, e2, e3);
                         store_dirs(r);
                     }
                     if (r + 1 < lenq) {
-                        fill_row_tri(Q, R, gend, 0, 0, prof + b1 * SA_PROF_STRIDE, prof + b2 * SA_PROF_STRIDE, sc0, sc0,
-                                     alo, ahi, blo, bhi);
+                        fill_row_tri_tag(Q, R, gend, 1, 0, prof + b1 * SA_PROF_STRIDE, prof + b2 * SA_PROF_STRIDE, sc0, sc0,
+                                         e0, e1, e2, e3);
                         store_dirs(r + 1);
                     }
                     b0 = b2; b1 = b3;
@@ -323,11 +342,11 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_kernel(const Sa
                 for (int r = 0; r < maxlen; r += 2) {
                     const int b2 = residue(r + 2), b3 = residue(r + 3);
                     if (r < lenq) {
-                        fill_row_adj(R, Q, gend, 0, 0, prof + (b0 < 20 ? b0 : 0) * 32, a4, alo, ahi, blo, bhi);
+                        fill_row_adj_tag(R, Q, gend, 1, 0, prof + (b0 < 20 ? b0 : 0) * 32, a4, e0, e1, e2, e3);
                         store_dirs(r);
                     }
                     if (r + 1 < lenq) {
-                        fill_row_adj(Q, R, gend, 0, 0, prof + (b1 < 20 ? b1 : 0) * 32, a4, alo, ahi, blo, bhi);
+                        fill_row_adj_tag(Q, R, gend, 1, 0, prof + (b1 < 20 ? b1 : 0) * 32, a4, e0, e1, e2, e3);
                         store_dirs(r + 1);
                     }
                     b0 = b2; b1 = b3;
@@ -343,6 +362,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_kernel(const Sa
                 for (int c = 0; c < SA_LP; c++)
                     if (c == lenp - 1) dlast = (lenq & 1) ? Q[c] : R[c];
             }
+            dlast >>= 2;      // banks hold 4*D + 1
             const int score = dlast + (lenp + lenq) * P.gap;
             __syncthreads();   // direction rows written by this wave are visible to its loads
 
@@ -362,7 +382,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_kernel(const Sa
                 for (int q4 = 0; q4 < 16; q4++) bw[q4] = 0;
             }
 #define SA_TRACEBACK(WW)                                                                                   \
-    traceback<MODE, WW>(lane, maxlen, lenq, lenp, 4 * gend, spill, bw, brow, acol, emask,                   \
+    traceback<MODE, WW>(lane, maxlen, lenq, lenp, spill, bw, brow, acol, emask,                   \
                         stage + lane * SA_LDS_STAGE_DWORDS, matches, gaps)
             if (wpr == 4) SA_TRACEBACK(4);
             else if (wpr == 3) SA_TRACEBACK(3);

@@ -42,6 +42,10 @@ constexpr int CHAINS = 8;
 #define K_PERM 23
 #define K_MADU24 24
 #define K_CELL_D 25
+#define K_CELL_SIGN 26
+#define K_CELL_TAG 27
+#define K_ALIGNBIT 28
+#define K_ANDOR 29
 
 template <int KIND>
 __global__ void __launch_bounds__(256) k_valu(unsigned* out, unsigned long long* cyc, unsigned seed) {
@@ -113,6 +117,29 @@ __global__ void __launch_bounds__(256) k_valu(unsigned* out, unsigned long long*
                 asm volatile("v_addc_co_u32_e64 %0, s[22:23], %0, %0, s[24:25]" : "+v"(g[k]) : : "s22", "s23", "s24", "s25");
                 a[k] = h;
             }
+            if (KIND == K_ALIGNBIT) asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(a[k]) : "v"(b));
+            if (KIND == K_ANDOR) asm volatile("v_and_or_b32 %0, %0, %1, 1" : "+v"(a[k]) : "v"(b));
+            if (KIND == K_CELL_SIGN) {
+                // add, max3, (sub, alignbit) x2: direction bits = sign bits of (m - h) and (up - h)
+                unsigned m, h, x, y;
+                asm volatile("v_add_u32 %0, %1, %2" : "=v"(m) : "v"(a[k]), "v"(b));
+                asm volatile("v_max3_i32 %0, %1, %2, %3" : "=v"(h) : "v"(m), "v"(c), "v"(d));
+                asm volatile("v_sub_u32 %0, %1, %2" : "=v"(x) : "v"(m), "v"(h));
+                asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(f[k]) : "v"(x));
+                asm volatile("v_sub_u32 %0, %1, %2" : "=v"(y) : "v"(c), "v"(h));
+                asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(g[k]) : "v"(y));
+                a[k] = h;
+            }
+            if (KIND == K_CELL_TAG) {
+                // values scaled by 4 with a 2-bit origin tag: add, max3, alignbit (2 tag bits), and, or
+                unsigned m, h, z;
+                asm volatile("v_add_u32 %0, %1, %2" : "=v"(m) : "v"(a[k]), "v"(b));
+                asm volatile("v_max3_i32 %0, %1, %2, %3" : "=v"(h) : "v"(m), "v"(c), "v"(d));
+                asm volatile("v_alignbit_b32 %0, %1, %0, 2" : "+v"(f[k]) : "v"(h));
+                asm volatile("v_and_b32 %0, -4, %1" : "=v"(z) : "v"(h));
+                asm volatile("v_or_b32 %0, 1, %1" : "=v"(a[k]) : "v"(z));
+                d = z;
+            }
             if (KIND == K_CELL_D) {
                 // 2-bit code per cell by arithmetic: add, max, max, sub, sub, add(+1), min3, lshl_or
                 unsigned m, h, x, y, cde;
@@ -168,6 +195,11 @@ int main() {
     printf("device %s CUs=%d clock=%.3f GHz\n", p.name, ncu, p.clockRate / 1e6);
     unsigned* d_out; CHECK(hipMalloc(&d_out, sizeof(unsigned) * ncu * 4 * 256));
     unsigned long long* d_cyc; CHECK(hipMalloc(&d_cyc, 8 * ncu * 4 * 4));
+    run<K_CELL_SIGN>("cell: add,max3,2x(sub,alignbit) (6)", 6, d_out, d_cyc, ncu);
+    run<K_CELL_TAG>("cell: add,max3,alignbit,and,or (5)", 5, d_out, d_cyc, ncu);
+    run<K_ALIGNBIT>("v_alignbit_b32", 1, d_out, d_cyc, ncu);
+    run<K_ANDOR>("v_and_or_b32", 1, d_out, d_cyc, ncu);
+    if (getenv("VALU_PEAK_SHORT")) return 0;
     run<K_ADD>("v_add_u32", 1, d_out, d_cyc, ncu);
     run<K_SUB>("v_sub_u32", 1, d_out, d_cyc, ncu);
     run<K_MAX>("v_max_i32", 1, d_out, d_cyc, ncu);
