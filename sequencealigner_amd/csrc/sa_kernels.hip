@@ -63,17 +63,6 @@ __device__ __forceinline__ uint32_t pick_word(const uint32_t (&W)[16], const int
     return v;
 }
 
-// dword i (per lane) of a direction row: 0 below the row, the last dword above it
-template <int W>
-__device__ __forceinline__ uint32_t dir_word(const uint4& d, const int i) {
-    uint32_t v = d.x;
-    if (i < 0) v = 0;
-    if (W == 2) { if (i >= 1) v = d.y; }
-    if (W == 3) { if (i == 1) v = d.y; if (i >= 2) v = d.z; }
-    if (W == 4) { if (i == 1) v = d.y; if (i == 2) v = d.z; if (i >= 3) v = d.w; }
-    return v;
-}
-
 template <int MODE, int W>
 __device__ __forceinline__ void traceback(const int lane, const int maxlen, const int lenq, const int lenp,
                                           const uint32_t* __restrict__ spill,
@@ -122,22 +111,15 @@ __device__ __forceinline__ void traceback(const int lane, const int maxlen, cons
                     const uint64_t x = v << ((64 - 2 * j) & 63);
                     L = x ? __builtin_clzll(x) : 64;
                 } else {
-                    // 32-bit window over dwords j/16 and j/16 - 1; a run of 16 or more LEFT moves that
-                    // has not reached column 0 goes on in the dwords below (rare)
-                    const int wi = j >> 4, sh = (2 * j) & 31;
-                    const uint32_t x = __builtin_amdgcn_alignbit(dir_word<W>(ck.d[k], wi), dir_word<W>(ck.d[k], wi - 1), sh);
-                    L = x ? __builtin_clz(x) : 32;
-                    bool more = (x == 0) && (j > 16);
-                    int below = 1;
-                    while (__any(more)) {
-                        if (more) {
-                            const uint32_t y = __builtin_amdgcn_alignbit(dir_word<W>(ck.d[k], wi - below),
-                                                                         dir_word<W>(ck.d[k], wi - below - 1), sh);
-                            L = 32 * below + (y ? __builtin_clz(y) : 32);
-                            below++;
-                            more = (y == 0) && (j > 16 * below);
-                        }
-                    }
+                    // columns 32..63 in one 64-bit half, 0..31 in the other; a run that starts in the
+                    // upper half and finds nothing there goes on from column 31
+                    const uint64_t v0 = ((uint64_t)ck.d[k].y << 32) | ck.d[k].x;
+                    const uint64_t v1 = ((uint64_t)ck.d[k].w << 32) | ck.d[k].z;
+                    const bool upper = j > 32;
+                    const int jj = upper ? j - 32 : j;
+                    const uint64_t x = (upper ? v1 : v0) << ((64 - 2 * jj) & 63);
+                    const int l0 = v0 ? __builtin_clzll(v0) : 64;
+                    L = x ? __builtin_clzll(x) : (upper ? 2 * jj + l0 : 64);
                 }
                 const int run = min(L >> 1, j);
                 j -= run;
