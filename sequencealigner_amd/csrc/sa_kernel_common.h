@@ -14,11 +14,6 @@
 
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
 
-// (hi:lo) >> sh, low 32 bits: shifting in the sign bit of lo with sh = 31
-__device__ __forceinline__ uint32_t shift_in_sign(uint32_t acc, int v) {
-    return __builtin_amdgcn_alignbit(acc, (uint32_t)v, 31);
-}
-
 __device__ __forceinline__ int wave_max(int v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
@@ -30,98 +25,7 @@ __device__ __forceinline__ int wave_min(int v) {
     return v;
 }
 
-// One DP cell.  up/diag come from the previous row's bank, left from this row's;
-// for column 0 they are diag0 / left0 (0 on the matrix border, the last column of
-// the previous 64-column strip otherwise).  The two direction bits are the sign
-// bits of (m - h) and (up - h).
-#define SA_CELL(IN, OUT, C, S, PA, PB)                                     \
-    {                                                                      \
-        const int diag_ = ((C) == 0) ? diag0 : IN[((C) == 0) ? 0 : (C) - 1];   \
-        const int left_ = ((C) == 0) ? left0 : OUT[((C) == 0) ? 0 : (C) - 1];  \
-        const int up_ = IN[C];                                             \
-        const int m_ = diag_ + (S);                                        \
-        const int h_ = max3i(m_, up_, left_);                              \
-        PA = shift_in_sign(PA, m_ - h_);                                   \
-        PB = shift_in_sign(PB, up_ - h_);                                  \
-        OUT[C] = h_;                                                       \
-    }
-
-// Four columns of a TRIANGULAR row.  CUR holds their substitution scores; the
-// scores of the next four columns are requested first so that the LDS latency
-// is covered by the 24 arithmetic instructions of this group (a row of the
-// profile is 68 dwords apart from the next, so the request after the last group
-// stays inside the row's padding).  Rows end early: gend = ceil(len1 / 4).
-#define SA_GROUP_TRI(G, CUR, NXT, PA, PB)                                          \
-    NXT = *reinterpret_cast<const int4*>(row_base + 4 * ((G) + 1));                \
-    __builtin_amdgcn_sched_barrier(0);                                             \
-    SA_CELL(IN, OUT, 4 * (G) + 0, CUR.x, PA, PB)                                   \
-    SA_CELL(IN, OUT, 4 * (G) + 1, CUR.y, PA, PB)                                   \
-    SA_CELL(IN, OUT, 4 * (G) + 2, CUR.z, PA, PB)                                   \
-    SA_CELL(IN, OUT, 4 * (G) + 3, CUR.w, PA, PB)                                   \
-    if (gend == (G) + 1) return;
-
-// One DP row of the TRIANGULAR kernel: IN = previous row, OUT = this row,
-// columns 0 .. 4*gend-1 (gend is wave-uniform).  sc_in = scores of columns 0..3
-// for this row; sc_out receives the same for the next row (requested at the top
-// of the row, used one row later).  The caller alternates two variables between
-// rows so that no register copies are needed at the loop edge.
-__device__ __forceinline__ void fill_row_tri(const int (&IN)[SA_LP], int (&OUT)[SA_LP], const int gend,
-                                             const int diag0, const int left0,
-                                             const int32_t* __restrict__ row_base,
-                                             const int32_t* __restrict__ next_row_base, const int4& sc_in,
-                                             int4& sc_out,
-                                             uint32_t& alo, uint32_t& ahi, uint32_t& blo, uint32_t& bhi) {
-    int4 scE = sc_in, scO;
-    sc_out = *reinterpret_cast<const int4*>(next_row_base);
-    SA_GROUP_TRI(0, scE, scO, alo, blo)
-    SA_GROUP_TRI(1, scO, scE, alo, blo)
-    SA_GROUP_TRI(2, scE, scO, alo, blo)
-    SA_GROUP_TRI(3, scO, scE, alo, blo)
-    SA_GROUP_TRI(4, scE, scO, alo, blo)
-    SA_GROUP_TRI(5, scO, scE, alo, blo)
-    SA_GROUP_TRI(6, scE, scO, alo, blo)
-    SA_GROUP_TRI(7, scO, scE, alo, blo)
-    SA_GROUP_TRI(8, scE, scO, ahi, bhi)
-    SA_GROUP_TRI(9, scO, scE, ahi, bhi)
-    SA_GROUP_TRI(10, scE, scO, ahi, bhi)
-    SA_GROUP_TRI(11, scO, scE, ahi, bhi)
-    SA_GROUP_TRI(12, scE, scO, ahi, bhi)
-    SA_GROUP_TRI(13, scO, scE, ahi, bhi)
-    SA_GROUP_TRI(14, scE, scO, ahi, bhi)
-    SA_GROUP_TRI(15, scO, scE, ahi, bhi)
-}
-
-// One DP row of the ADJACENT kernel (every lane has its own column sequence):
-// scores come from an LDS copy of S', row selected by the row residue, entry by
-// the column residue (a4 = 4 * residue code).
-__device__ __forceinline__ void fill_row_adj(const int (&IN)[SA_LP], int (&OUT)[SA_LP], const int gend,
-                                             const int diag0, const int left0,
-                                             const int32_t* __restrict__ row_base, const int (&a4)[SA_LP],
-                                             uint32_t& alo, uint32_t& ahi, uint32_t& blo, uint32_t& bhi) {
-    const char* rb = reinterpret_cast<const char*>(row_base);
-#pragma unroll
-    for (int g = 0; g < SA_LP / 4; g++) {
-        if (g < gend) {   // wave-uniform
-            const int s0 = *reinterpret_cast<const int32_t*>(rb + a4[4 * g + 0]);
-            const int s1 = *reinterpret_cast<const int32_t*>(rb + a4[4 * g + 1]);
-            const int s2 = *reinterpret_cast<const int32_t*>(rb + a4[4 * g + 2]);
-            const int s3 = *reinterpret_cast<const int32_t*>(rb + a4[4 * g + 3]);
-            if (g < 8) {
-                SA_CELL(IN, OUT, 4 * g + 0, s0, alo, blo)
-                SA_CELL(IN, OUT, 4 * g + 1, s1, alo, blo)
-                SA_CELL(IN, OUT, 4 * g + 2, s2, alo, blo)
-                SA_CELL(IN, OUT, 4 * g + 3, s3, alo, blo)
-            } else {
-                SA_CELL(IN, OUT, 4 * g + 0, s0, ahi, bhi)
-                SA_CELL(IN, OUT, 4 * g + 1, s1, ahi, bhi)
-                SA_CELL(IN, OUT, 4 * g + 2, s2, ahi, bhi)
-                SA_CELL(IN, OUT, 4 * g + 3, s3, ahi, bhi)
-            }
-        }
-    }
-}
-
-// ---- tagged cells (peptide kernel) ------------------------------------------
+// ---- tagged cells --------------------------------------------------------------
 // Values are kept as 4*D plus a 2-bit tag, and the tag of the winning operand
 // of the max3 tells the traceback where the cell came from:
 //   diagonal operand  4*(Dd + S') + 3     (bank value 4*Dd + 1 plus table entry 4*S' + 2)
@@ -133,8 +37,7 @@ __device__ __forceinline__ void fill_row_adj(const int (&IN)[SA_LP], int (&OUT)[
 // moves (clz / 2) and what ends it (clz odd: UP, even: DIAG).
 // Per cell: add, max3, alignbit (the two tag bits go into the row's direction
 // word), and (left operand of the next column), or (bank value for the next row)
-// -- five instructions, two of them on the slow issue path, against six with
-// three slow ones for the sign-bit scheme.
+// -- five instructions, two of them (max3, alignbit) on the slow issue path.
 #define SA_TAG_LEFT 0
 #define SA_TAG_UP 1
 #define SA_TAG_DIAG 3
@@ -150,6 +53,11 @@ __device__ __forceinline__ void fill_row_adj(const int (&IN)[SA_LP], int (&OUT)[
         OUT[C] = zl | 1;                                                         \
     }
 
+// Four columns of a TRIANGULAR row.  CUR holds their table entries; the entries of
+// the next four columns are requested first so that the LDS latency is covered by
+// the arithmetic of this group (a row of the profile is 68 dwords apart from the
+// next, so the request after the last group stays inside the row's padding).
+// Rows end early: gend = ceil(len1 / 4).
 #define SA_GROUP_TAG(G, CUR, NXT, ACC)                                             \
     NXT = *reinterpret_cast<const int4*>(row_base + 4 * ((G) + 1));                \
     __builtin_amdgcn_sched_barrier(0);                                             \
@@ -159,10 +67,12 @@ __device__ __forceinline__ void fill_row_adj(const int (&IN)[SA_LP], int (&OUT)[
     SA_CELL_TAG(IN, OUT, 4 * (G) + 3, CUR.w, ACC)                                  \
     if (gend == (G) + 1) return;
 
-// One row of tagged cells, TRIANGULAR operands (see fill_row_tri for the protocol of
-// row_base / next_row_base / sc_in / sc_out).  IN and OUT hold 4*D + 1; diag0 is the
-// border value in that form (1 on the matrix border), left0 the border value with
-// the tag cleared (0).  e[q] receives the tags of columns 16q .. 16q+15, newest on
+// One row of tagged cells, TRIANGULAR operands: IN = previous row, OUT = this row,
+// columns 0 .. 4*gend-1 (gend is wave-uniform).  sc_in = table entries of columns
+// 0..3 for this row; sc_out receives the same for the next row (requested at the top
+// of the row, used one row later).  IN and OUT hold 4*D + 1; diag0 is the border
+// value in that form (1 on the matrix border), left0 the border value with the tag
+// cleared (0).  e[q] receives the tags of columns 16q .. 16q+15, newest on
 // top: after k cells column 16q + i sits at bits 32 - 2(k - i).
 __device__ __forceinline__ void fill_row_tri_tag(const int (&IN)[SA_LP], int (&OUT)[SA_LP], const int gend,
                                                  const int diag0, const int left0,

@@ -2,12 +2,13 @@
 // than 64 residues (proteins) on gfx950, still one pair per lane.
 //
 // Same arithmetic as the peptide kernel (see sa_kernels.hip: D = H - (i+j)*gap,
-// one add + one max3 per cell, direction bits from sign bits).  The matrix is
+// tagged cells of five instructions, sa_kernel_common.h).  The matrix is
 // swept in vertical strips of 64 columns: inside a strip the DP row lives in
 // two alternating banks of 64 VGPRs exactly as in the peptide kernel; the last
 // column of a strip is written per row to a small global buffer and read back
-// as the left border of the next strip.  Direction bits (16 bytes per lane, row
-// and strip) go to a per-workgroup global area, 1 KiB per wave and row,
+// as the left border of the next strip.  Direction tags (16 bytes per lane, row
+// and strip: column c of the strip at bits 2(c%16) of dword c/16) go to a
+// per-workgroup global area, 1 KiB per wave and row,
 // coalesced.  The traceback reads, for every row, the 16 bytes of the strip its
 // column is in; a run of LEFT moves may continue into the strip on the left.
 // The per-row output is a uint16 (LEFT moves * 2 + DIAG/UP).
@@ -31,7 +32,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_kernel(const SaPep
     if (MODE == SA_MODE_ADJ) {
         for (int e = lane; e < 20 * 32; e += 64) {
             const int b = e >> 5, a = e & 31;
-            prof[e] = (a <= 20) ? P.sprime[a * SA_SPRIME_STRIDE + b] : 0;
+            prof[e] = SA_TAG_TABLE((a <= 20) ? P.sprime[a * SA_SPRIME_STRIDE + b] : 0);
         }
         __syncthreads();
     }
@@ -115,8 +116,8 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_kernel(const SaPep
                     const int a = acol[64 * s + lane];
                     __syncthreads();
 #pragma unroll
-                    for (int b = 0; b < 20; b++) prof[b * SA_PROF_STRIDE + lane] = P.sprime[a * SA_SPRIME_STRIDE + b];
-                    prof[20 * SA_PROF_STRIDE + lane] = 0;
+                    for (int b = 0; b < 20; b++) prof[b * SA_PROF_STRIDE + lane] = SA_TAG_TABLE(P.sprime[a * SA_SPRIME_STRIDE + b]);
+                    prof[20 * SA_PROF_STRIDE + lane] = SA_TAG_TABLE(0);
                     __syncthreads();
 #pragma unroll
                     for (int c = 0; c < SA_LP; c++) a4[c] = 0;
@@ -133,18 +134,23 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_kernel(const SaPep
                 }
                 int R[SA_LP], Q[SA_LP];
 #pragma unroll
-                for (int c = 0; c < SA_LP; c++) { R[c] = 0; Q[c] = 0; }
-                uint32_t alo = 0, ahi = 0, blo = 0, bhi = 0;
+                for (int c = 0; c < SA_LP; c++) { R[c] = 1; Q[c] = 1; }     // border row: 4*0 + 1
+                uint32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;
                 const int32_t* bin = bcol + (size_t)(s & 1) * rows_cap * 64 + lane;
                 int32_t* bout = bcol + (size_t)((s + 1) & 1) * rows_cap * 64 + lane;
                 uint32_t* drow = dirs + ((size_t)s * rows_cap * 64 + lane) * 4;
                 const bool first_strip = s == 0, more_strips = s + 1 < nstrips;
+                // the last dword a row writes took 4*gend - 16*(wl) cells: its first column is moved down to bit 0
+                const int wl = (gend - 1) >> 2;
+                const int lsh = 32 - 2 * (4 * gend - 16 * wl);
+                const int sh0 = wl == 0 ? lsh : 0, sh1 = wl == 1 ? lsh : 0, sh2 = wl == 2 ? lsh : 0, sh3 = wl == 3 ? lsh : 0;
 
                 auto residue = [&](int r) -> int { return (int)brow[(size_t)min(r, last_row) * bstep]; };
-                auto border = [&](int r) -> int { return first_strip ? 0 : bin[(size_t)min(r, last_row) * 64]; };
+                // last column of the previous strip in bank form (4*D + 1); 1 on the matrix border
+                auto border = [&](int r) -> int { return first_strip ? 1 : bin[(size_t)min(r, last_row) * 64]; };
                 int b0 = residue(0), b1 = residue(1);
                 int l0 = border(0), l1 = border(1);
-                int dprev = 0;                                   // left border value of the previous row = diag of column 0
+                int dprev = 1;                                   // border value of the previous row = diag of column 0
                 int4 sc0 = make_int4(0, 0, 0, 0), sc1 = sc0;
                 if (MODE == SA_MODE_TRI) sc0 = *reinterpret_cast<const int4*>(prof + b0 * SA_PROF_STRIDE);
                 for (int r = 0; r < maxlen; r += 2) {
@@ -152,20 +158,20 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_kernel(const SaPep
                     const int l2 = border(r + 2), l3 = border(r + 3);
                     if (r < lenq) {
                         if (MODE == SA_MODE_TRI)
-                            fill_row_tri(R, Q, gend, dprev, l0, prof + b0 * SA_PROF_STRIDE, prof + b1 * SA_PROF_STRIDE, sc0, sc1,
-                                         alo, ahi, blo, bhi);
+                            fill_row_tri_tag(R, Q, gend, dprev, l0 - 1, prof + b0 * SA_PROF_STRIDE, prof + b1 * SA_PROF_STRIDE, sc0, sc1,
+                                             e0, e1, e2, e3);
                         else
-                            fill_row_adj(R, Q, gend, dprev, l0, prof + (b0 < 20 ? b0 : 0) * 32, a4, alo, ahi, blo, bhi);
-                        *reinterpret_cast<uint4*>(drow + (size_t)r * 256) = make_uint4(alo, ahi, blo, bhi);
+                            fill_row_adj_tag(R, Q, gend, dprev, l0 - 1, prof + (b0 < 20 ? b0 : 0) * 32, a4, e0, e1, e2, e3);
+                        *reinterpret_cast<uint4*>(drow + (size_t)r * 256) = make_uint4(e0 >> sh0, e1 >> sh1, e2 >> sh2, e3 >> sh3);
                         if (more_strips) bout[(size_t)r * 64] = Q[SA_LP - 1];
                     }
                     if (r + 1 < lenq) {
                         if (MODE == SA_MODE_TRI)
-                            fill_row_tri(Q, R, gend, l0, l1, prof + b1 * SA_PROF_STRIDE, prof + b2 * SA_PROF_STRIDE, sc1, sc0,
-                                         alo, ahi, blo, bhi);
+                            fill_row_tri_tag(Q, R, gend, l0, l1 - 1, prof + b1 * SA_PROF_STRIDE, prof + b2 * SA_PROF_STRIDE, sc1, sc0,
+                                             e0, e1, e2, e3);
                         else
-                            fill_row_adj(Q, R, gend, l0, l1, prof + (b1 < 20 ? b1 : 0) * 32, a4, alo, ahi, blo, bhi);
-                        *reinterpret_cast<uint4*>(drow + (size_t)(r + 1) * 256) = make_uint4(alo, ahi, blo, bhi);
+                            fill_row_adj_tag(Q, R, gend, l0, l1 - 1, prof + (b1 < 20 ? b1 : 0) * 32, a4, e0, e1, e2, e3);
+                        *reinterpret_cast<uint4*>(drow + (size_t)(r + 1) * 256) = make_uint4(e0 >> sh0, e1 >> sh1, e2 >> sh2, e3 >> sh3);
                         if (more_strips) bout[(size_t)(r + 1) * 64] = R[SA_LP - 1];
                     }
                     dprev = l1;
@@ -185,7 +191,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_kernel(const SaPep
                 }
                 __syncthreads();   // border column and direction rows are complete before anyone reads them
             }
-            const int score = dfinal + (lenp + lenq) * P.gap;
+            const int score = (dfinal >> 2) + (lenp + lenq) * P.gap;      // banks hold 4*D + 1
 
             // --------------------------------------------------------- traceback
             uint8_t* rec = out_row + (size_t)rel * P.stride;
@@ -198,25 +204,22 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_kernel(const SaPep
                     if (r < lenq) {
                         int run_total = 0, t = 1;
                         while (j > 0) {
-                            const int sj = (j - 1) >> 6, cj = (j - 1) & 63;
+                            // tags of the strip column j-1 is in; L = leading zeros from that column down =
+                            // 2 * (LEFT moves) + (1 if an UP ends the run, 0 if a DIAG does)
+                            const int sj = (j - 1) >> 6, jl = ((j - 1) & 63) + 1;
                             const uint4 d = *reinterpret_cast<const uint4*>(dirs + (((size_t)sj * rows_cap + r) * 64 + lane) * 4);
-                            const int ncols = (sj == nstrips - 1) ? 4 * gend_last : 64;
-                            uint64_t A, B;
-                            if (ncols > 32) {
-                                const int nhi = ncols - 32;
-                                const uint32_t himask = (uint32_t)((1ull << nhi) - 1);
-                                A = ((uint64_t)d.x << nhi) | (d.y & himask);
-                                B = ((uint64_t)d.z << nhi) | (d.w & himask);
-                            } else {
-                                A = d.x; B = d.z;
-                            }
-                            const uint64_t x = ~((A & B) >> (ncols - 1 - cj));   // zero bit = first column that is not LEFT
-                            int run = x ? __builtin_ctzll(x) : 64;
-                            run = min(run, cj + 1);
+                            const uint64_t v0 = ((uint64_t)d.y << 32) | d.x;
+                            const uint64_t v1 = ((uint64_t)d.w << 32) | d.z;
+                            const bool upper = jl > 32;
+                            const int jj = upper ? jl - 32 : jl;
+                            const uint64_t x = (upper ? v1 : v0) << ((64 - 2 * jj) & 63);
+                            const int lz0 = v0 ? __builtin_clzll(v0) : 64;
+                            const int L = x ? __builtin_clzll(x) : (upper ? 2 * jj + lz0 : 64);
+                            const int run = min(L >> 1, jl);
                             j -= run;
                             run_total += run;
-                            if (run == cj + 1 && j > 0) continue;                 // the run goes on in the strip to the left
-                            if (j > 0) t = (int)((A >> (ncols - 1 - ((j - 1) & 63))) & 1);
+                            if (run == jl && j > 0) continue;                     // the run goes on in the strip to the left
+                            if (run < jl) t = L & 1;
                             break;
                         }
                         if (t == 0) {
