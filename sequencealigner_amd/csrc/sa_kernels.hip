@@ -38,6 +38,15 @@
 
 #include "sa_kernel_common.h"
 
+// Buffer descriptors (base, byte count) for the arrays the row loops touch: a buffer
+// access takes a wave-uniform byte offset in an SGPR and a per-lane 32-bit offset in a
+// VGPR, so the row loops spend no vector instructions on addresses; accesses past the
+// byte count are dropped by the hardware.
+typedef uint32_t sa_u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t sa_u32x3 __attribute__((ext_vector_type(3)));
+typedef uint32_t sa_u32x4 __attribute__((ext_vector_type(4)));
+#define SA_BUFFER_FLAGS 0x00020000
+
 // ---------------------------------------------------------------- traceback
 // Bottom row first, four rows per chunk.  The direction words of a chunk are
 // requested two chunks ahead of their use (global spill area, coalesced).  A row
@@ -65,11 +74,12 @@ __device__ __forceinline__ uint32_t pick_word(const uint32_t (&W)[16], const int
 
 template <int MODE, int W>
 __device__ __forceinline__ void traceback(const int lane, const int maxlen, const int lenq, const int lenp,
-                                          const uint32_t* __restrict__ spill,
+                                          const __amdgpu_buffer_rsrc_t spill,
                                           const uint32_t (&bw)[16], const uint8_t* __restrict__ brow,
                                           const uint8_t* __restrict__ acol, const uint64_t* __restrict__ emask,
                                           uint32_t* __restrict__ stage_rec, int& matches_out, int& gaps_out) {
     int j = lenp, matches = 0, gaps = 0;
+    const int lane_off = lane * W * 4;
 
     // Nothing loaded here is used before process().  Row indices past the end of
     // the longest sequence are clamped, so the requests need no guard.
@@ -77,13 +87,19 @@ __device__ __forceinline__ void traceback(const int lane, const int maxlen, cons
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int r = min(4 * ch + k, maxlen - 1);   // wave-uniform
-            const uint32_t* src = spill + (r * 64 + lane) * W;
-            if (W == 4) ck.d[k] = *reinterpret_cast<const uint4*>(src);
-            else if (W == 3) ck.d[k] = make_uint4(src[0], src[1], src[2], 0);
-            else if (W == 2) {
-                const uint2 t2 = *reinterpret_cast<const uint2*>(src);
-                ck.d[k] = make_uint4(t2.x, t2.y, 0, 0);
-            } else ck.d[k] = make_uint4(src[0], 0, 0, 0);
+            const int row_off = r * 256 * W;
+            if (W == 4) {
+                const sa_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(spill, lane_off, row_off, 0);
+                ck.d[k] = make_uint4(v.x, v.y, v.z, v.w);
+            } else if (W == 3) {
+                const sa_u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(spill, lane_off, row_off, 0);
+                ck.d[k] = make_uint4(v.x, v.y, v.z, 0);
+            } else if (W == 2) {
+                const sa_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(spill, lane_off, row_off, 0);
+                ck.d[k] = make_uint4(v.x, v.y, 0, 0);
+            } else {
+                ck.d[k] = make_uint4(__builtin_amdgcn_raw_buffer_load_b32(spill, lane_off, row_off, 0), 0, 0, 0);
+            }
         }
         ck.b4 = (MODE == SA_MODE_ADJ) ? reinterpret_cast<const uint32_t*>(brow)[ch] : 0;
     };
@@ -167,7 +183,11 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_kernel(const Sa
     uint64_t* const emask = reinterpret_cast<uint64_t*>(smem + SA_LDS_PROF_BYTES);
     uint32_t* const stage = reinterpret_cast<uint32_t*>(smem + SA_LDS_PROF_BYTES + SA_LDS_EMASK_BYTES);
     const int lane = threadIdx.x;
-    uint32_t* const spill = P.spill + (size_t)blockIdx.x * P.spill_rows * 256;
+    const __amdgpu_buffer_rsrc_t spill = __builtin_amdgcn_make_buffer_rsrc(
+        P.spill + (size_t)blockIdx.x * P.spill_rows * 256, 0, P.spill_rows * 1024, SA_BUFFER_FLAGS);
+    // residue codes by position (TRIANGULAR): row r of the transposed table is npad bytes long
+    const __amdgpu_buffer_rsrc_t codes_t = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t*>(P.codes_t), 0, (MODE == SA_MODE_TRI) ? SA_LP * P.npad : 0, SA_BUFFER_FLAGS);
     const uint32_t cpr = P.stride >> 4;   // 16-byte chunks per record
     // optional phase timers (diagnostic builds of the caller pass a buffer): 0 fetch, 1 profile, 2 operands, 3 fill, 4 traceback, 5 store
     const bool timed = P.phase_cycles != nullptr;
@@ -289,15 +309,28 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_kernel(const Sa
             uint32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;
 
             // rows past the end of a sequence read padding (codes_t and the slots are 64 positions long)
-            auto residue = [&](int r) -> int { return (int)brow[min(r, SA_LP - 1) * bstep]; };
+            auto residue = [&](int r) -> int {
+                if (MODE == SA_MODE_TRI)
+                    return (int)__builtin_amdgcn_raw_buffer_load_b8(codes_t, sidx_l, min(r, SA_LP - 1) * (int)P.npad, 0);
+                return (int)brow[min(r, SA_LP - 1) * bstep];
+            };
             // the last dword of a row took ncols - 16*(wpr-1) cells: move its first column down to bit 0
             const int lsh = 32 - 2 * (4 * gend - 16 * (wpr - 1));
+            const int dir_lane = lane * wpr * 4;      // byte offset of this lane inside a direction row
             auto store_dirs = [&](int r) {
-                uint32_t* dst = spill + (r * 64 + lane) * wpr;
-                if (wpr == 4) *reinterpret_cast<uint4*>(dst) = make_uint4(e0, e1, e2, e3 >> lsh);
-                else if (wpr == 3) { dst[0] = e0; dst[1] = e1; dst[2] = e2 >> lsh; }
-                else if (wpr == 2) *reinterpret_cast<uint2*>(dst) = make_uint2(e0, e1 >> lsh);
-                else dst[0] = e0 >> lsh;
+                const int row_off = r * 256 * wpr;
+                if (wpr == 4) {
+                    const sa_u32x4 v = {e0, e1, e2, e3 >> lsh};
+                    __builtin_amdgcn_raw_buffer_store_b128(v, spill, dir_lane, row_off, 0);
+                } else if (wpr == 3) {
+                    const sa_u32x3 v = {e0, e1, e2 >> lsh};
+                    __builtin_amdgcn_raw_buffer_store_b96(v, spill, dir_lane, row_off, 0);
+                } else if (wpr == 2) {
+                    const sa_u32x2 v = {e0, e1 >> lsh};
+                    __builtin_amdgcn_raw_buffer_store_b64(v, spill, dir_lane, row_off, 0);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b32(e0 >> lsh, spill, dir_lane, row_off, 0);
+                }
             };
 
             int b0 = residue(0), b1 = residue(1);
