@@ -119,6 +119,11 @@ int sa_fetch_resident(sa_ctx* ctx, uint64_t first, uint64_t n, uint8_t* dst);
 /* tuning knobs of the peptide kernel: 64-pair tiles per work item, workgroups (waves)
  * per CU; 0 keeps the current value */
 int sa_set_tuning(sa_ctx* ctx, uint32_t tiles_per_item, uint32_t wg_per_cu);
+/* TRIANGULAR peptides (no sequence above 64) normally run on a kernel that handles two first
+ * sequences per wave in packed 16-bit cells; it is used only when the substitution table allows
+ * it (0 <= S - 2*gap <= 120 everywhere).  enable = 0 forces one first sequence per wave, 32-bit
+ * cells (same results; for comparisons and tests).  Default: enabled. */
+int sa_set_pairing(sa_ctx* ctx, int enable);
 
 /* diagnostic: with enable != 0 the next launches accumulate shader cycles per kernel
  * phase (0 queue fetch, 1 profile build, 2 operand set-up, 3 fill, 4 traceback,
@@ -126,10 +131,11 @@ int sa_set_tuning(sa_ctx* ctx, uint32_t tiles_per_item, uint32_t wg_per_cu);
  * the previous launch.  Timed launches run a few percent slower. */
 int sa_debug_phase_cycles(sa_ctx* ctx, int enable, uint64_t totals[8]);
 /* diagnostic: the work list the kernels would pull for rows [row_begin,row_end), eight
- * uint32 per item {p, v0, count, b0, c0, 0, 0, 0}.  TRIANGULAR: first sequence p
+ * uint32 per item {p, v0, count, b0, c0, p2, 0, 0}.  TRIANGULAR: first sequence p
  * against entries [v0, v0 + 64*count) of its valid list, i.e. of the sequences with a
- * larger file index taken in bucket order (sa_debug_bucket_order); ADJACENT: pairs
- * p .. p+count-1. */
+ * larger file index taken in bucket order (sa_debug_bucket_order); with pairing, p2 is
+ * either 0xFFFFFFFF or a second first sequence (p2 > p) aligned against those of the
+ * same entries whose file index is above p2.  ADJACENT: pairs p .. p+count-1 (p2 = 0). */
 int sa_debug_work_items(sa_ctx* ctx, int schedule, uint64_t row_begin, uint64_t row_end,
                         uint32_t* items8, uint64_t cap, uint64_t* count);
 /* diagnostic: file index of every sequence in bucket order (length bucket, then file index) */

@@ -109,6 +109,7 @@ SIGNATURES = {
     "sa_run_resident": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "sa_fetch_resident": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, _u8p]),
     "sa_set_tuning": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
+    "sa_set_pairing": (C.c_int, [C.c_void_p, C.c_int]),
     "sa_expand_record": (
         C.c_int,
         [_u8p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_char_p, C.c_char_p,
@@ -265,6 +266,10 @@ class Aligner:
 
     def set_tuning(self, tiles_per_item=0, wg_per_cu=0):
         _check(self._lib.sa_set_tuning(self._ctx, tiles_per_item, wg_per_cu))
+
+    def set_pairing(self, enable):
+        """Two first sequences per wave in the TRIANGULAR peptide kernel (default on); off = one, 32-bit cells."""
+        _check(self._lib.sa_set_pairing(self._ctx, 1 if enable else 0))
 
     # -- dispatch
     def submit(self, schedule, r0, r1):

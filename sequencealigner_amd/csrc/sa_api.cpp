@@ -20,6 +20,7 @@ extern "C" void sa_launch_peptide(int mode, int waves_per_simd, const SaPepParam
                                   unsigned lds_bytes, hipStream_t stream);
 extern "C" void sa_launch_pack_slots(const uint8_t* codes, const uint64_t* offs, const uint32_t* lens, uint64_t nseq,
                                      uint64_t nslots, uint32_t lslot, uint8_t* slots, uint16_t* len16, hipStream_t stream);
+extern "C" void sa_launch_peptide_pair(int ng, const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream);
 extern "C" void sa_launch_long(int mode, const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream);
 
 namespace {
@@ -92,6 +93,7 @@ struct Work {                 // one submitted (or prepared) row range
     int schedule = 0;
     uint64_t first_pair = 0, npairs = 0;
     bool busy = false;
+    bool paired = false;      // items were built for the paired kernel
 };
 
 }  // namespace
@@ -106,6 +108,9 @@ struct sa_ctx {
     // tuning
     uint32_t tiles_per_item = 8;
     uint32_t wg_per_cu = 12;
+    bool pairing = true;               // TRIANGULAR peptides: two first sequences per wave where the table allows it
+    bool table_fits_i16 = false;       // 0 <= S' <= 120: packed 16-bit cells cannot overflow
+    uint32_t bucket_width = 1;
     // sequences (host mirror)
     uint64_t nseq = 0;
     std::vector<uint16_t> len;         // file order
@@ -136,6 +141,16 @@ namespace {
 
 uint64_t tri_row_start(uint64_t n, uint64_t i) { return i * (2 * n - i - 1) / 2; }
 
+// The paired kernel keeps 4*D + 3 in 16 bits with D <= 64 * max S' (S' = S - 2*gap, 64 = longest
+// peptide) and adds table entries as unsigned halves: it needs 0 <= S' <= 120.
+bool table_fits_i16(const int32_t* S, int32_t gap) {
+    for (int k = 0; k < 400; k++) {
+        const int64_t sp = (int64_t)S[k] - 2 * (int64_t)gap;
+        if (sp < 0 || sp > 120) return false;
+    }
+    return true;
+}
+
 // Bucket order of the sequences and the cursor table (see sa_device.h); TRIANGULAR only.
 int ensure_triangular(sa_ctx* c) {
     if (c->tri_ready) return SA_OK;
@@ -147,6 +162,7 @@ int ensure_triangular(sa_ctx* c) {
     const uint32_t nb = (range + width - 1) / width;
     if ((uint64_t)nb * n > (1ull << 28)) return SA_ERR_NOMEM;   // cursor table of more than 1 GiB
     c->nb = nb;
+    c->bucket_width = width;
     std::vector<uint32_t> count(nb + 1, 0);
     std::vector<uint16_t> bucket_of(n);
     for (uint64_t s = 0; s < n; s++) {
@@ -196,6 +212,11 @@ int ensure_triangular(sa_ctx* c) {
     return SA_OK;
 }
 
+bool is_long(const sa_ctx* c) { return c->lslot > SA_LP; }
+
+// TRIANGULAR work of a peptide context runs on the paired kernel (two first sequences per wave)
+bool uses_pairs(const sa_ctx* c) { return c->pairing && c->table_fits_i16 && !is_long(c); }
+
 int build_items(sa_ctx* c, int schedule, uint64_t r0, uint64_t r1, std::vector<SaItem>& items) {
     items.clear();
     SaItem it;
@@ -211,7 +232,8 @@ int build_items(sa_ctx* c, int schedule, uint64_t r0, uint64_t r1, std::vector<S
     int rc = ensure_triangular(c);
     if (rc) return rc;
     const uint32_t nb = c->nb, per = std::max(1u, c->tiles_per_item);
-    for (uint64_t p = r0; p < r1; p++) {
+    // items of first sequence p (and, in the paired kernel, of a second one p2 > p that rides along)
+    auto emit = [&](uint64_t p, uint32_t p2) {
         const uint32_t nvalid = (uint32_t)(c->nseq - 1 - p);
         const uint32_t* cur = &c->cursor[(size_t)p * nb];
         uint32_t b = 0, cum = 0;
@@ -226,17 +248,35 @@ int build_items(sa_ctx* c, int schedule, uint64_t r0, uint64_t r1, std::vector<S
             it.p = (uint32_t)p; it.v0 = v0;
             it.count = std::min(per, (nvalid - v0 + 63) / 64);
             it.b0 = b; it.c0 = cum;
+            it.reserved[0] = p2;
             items.push_back(it);
+        }
+    };
+    if (!uses_pairs(c)) {
+        for (uint64_t p = r0; p < r1; p++) emit(p, SA_INVALID_FI);
+        return SA_OK;
+    }
+    // first sequences of the same length bucket go two by two, in file order; the valid list of the
+    // earlier one contains the later one's
+    std::vector<std::pair<uint32_t, uint32_t>> order;
+    order.reserve(r1 - r0);
+    for (uint64_t p = r0; p < r1; p++) order.push_back({(uint32_t)((c->len[p] - c->min_seq) / c->bucket_width), (uint32_t)p});
+    std::sort(order.begin(), order.end());
+    for (size_t k = 0; k < order.size();) {
+        if (k + 1 < order.size() && order[k + 1].first == order[k].first) {
+            emit(order[k].second, order[k + 1].second);
+            k += 2;
+        } else {
+            emit(order[k].second, SA_INVALID_FI);
+            k += 1;
         }
     }
     return SA_OK;
 }
 
-bool is_long(const sa_ctx* c) { return c->lslot > SA_LP; }
-
 // global scratch of one workgroup: direction rows (and, for long sequences, the strip border columns)
 size_t spill_bytes_per_wg(const sa_ctx* c) {
-    if (!is_long(c)) return (size_t)SA_LP * 1024;
+    if (!is_long(c)) return (size_t)2 * SA_LP * 1024;      // two sets of direction rows for the paired kernel
     return (size_t)(c->lslot / 64) * c->lslot * 1024;
 }
 
@@ -248,7 +288,7 @@ uint32_t grid_for(const sa_ctx* c) {
         uint64_t g = std::min<uint64_t>((uint64_t)c->ncu * 8, budget / spill_bytes_per_wg(c));
         return (uint32_t)std::max<uint64_t>(1, g);
     }
-    const uint32_t lds = SA_LDS_FIXED_BYTES;
+    const uint32_t lds = SA_LDS_FIXED_BYTES + SA_LDS_EMASK_BYTES;
     uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>(c->wg_per_cu, (160u * 1024u) / lds));
     return (uint32_t)c->ncu * per_cu;
 }
@@ -289,7 +329,7 @@ int launch_work(sa_ctx* c, Work& w, bool timed) {
     P.stride = c->stride;
     P.out_base_pair = w.first_pair;
     P.spill = (uint32_t*)c->d_spill.p;
-    P.spill_rows = SA_LP;
+    P.spill_rows = 2 * SA_LP;
     P.nseq = (uint32_t)c->nseq;
     P.gap = c->gap;
     if (c->phase_timers) {
@@ -302,6 +342,8 @@ int launch_work(sa_ctx* c, Work& w, bool timed) {
     P.bcol = (int32_t*)c->d_bcol.p;
     if (is_long(c))
         sa_launch_long(w.schedule == SA_SCHEDULE_TRIANGULAR ? 0 : 1, &P, grid, SA_LDS_PROF_BYTES, c->compute);
+    else if (w.schedule == SA_SCHEDULE_TRIANGULAR && w.paired)
+        sa_launch_peptide_pair(c->max_seq <= 52 ? 13 : 16, &P, grid, SA_LDS_FIXED_BYTES + SA_LDS_EMASK_BYTES, c->compute);
     else
         sa_launch_peptide(w.schedule == SA_SCHEDULE_TRIANGULAR ? 0 : 1, c->wg_per_cu > 8 ? 3 : 2, &P, grid,
                           SA_LDS_FIXED_BYTES, c->compute);
@@ -315,6 +357,7 @@ int prepare_work(sa_ctx* c, Work& w, int schedule, uint64_t r0, uint64_t r1, boo
     int rc = build_items(c, schedule, r0, r1, items);
     if (rc) return rc;
     w.schedule = schedule;
+    w.paired = schedule == SA_SCHEDULE_TRIANGULAR && uses_pairs(c);
     w.first_pair = sa_pair_index(c, schedule, r0);
     w.npairs = sa_pair_count(c, schedule, r0, r1);
     w.nitems = (uint32_t)items.size();
@@ -402,6 +445,7 @@ int sa_init(sa_ctx** out, const int32_t* S, int32_t gap, uint32_t max_seq_len, i
         if (S) memcpy(h->S, S, sizeof(h->S)); else sa_default_matrix(h->S);
         h->gap = gap;
         h->max_len = max_seq_len;
+        h->table_fits_i16 = table_fits_i16(h->S, gap);
         *out = h;
         return SA_OK;
     }
@@ -419,6 +463,7 @@ int sa_init(sa_ctx** out, const int32_t* S, int32_t gap, uint32_t max_seq_len, i
     if (S) memcpy(c->S, S, sizeof(c->S)); else sa_default_matrix(c->S);
     c->gap = gap;
     c->max_len = max_seq_len;
+    c->table_fits_i16 = table_fits_i16(c->S, gap);
     int rc = SA_OK;
     do {
         if ((e = hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking)) != hipSuccess) { rc = hip_code(e); break; }
@@ -666,6 +711,14 @@ int sa_fetch_resident(sa_ctx* c, uint64_t first, uint64_t n, uint8_t* dst) {
     if (n)
         SA_HIP_TRY(hipMemcpy(dst, (const uint8_t*)c->resident.out.p + first * c->stride, n * (size_t)c->stride,
                              hipMemcpyDeviceToHost));
+    return SA_OK;
+}
+
+int sa_set_pairing(sa_ctx* c, int enable) {
+    if (!c) return SA_ERR_ARG;
+    if (c->inflight) return SA_ERR_STATE;
+    c->pairing = enable != 0;
+    c->resident_ready = false;
     return SA_OK;
 }
 

@@ -151,23 +151,25 @@ def test_expand_record_rejects_garbage():
 
 def _pairs_of_items(items, order, schedule):
     out = []
-    valid_cache = {}
-    for p, v0, count, _b0, _c0, _x, _y, _z in items.tolist():
+    for p, v0, count, _b0, _c0, p2, _y, _z in items.tolist():
         if schedule == sa.ADJACENT:
             out.extend((p + l, p + l + 1) for l in range(count))
         else:
-            if p not in valid_cache:
-                valid_cache = {p: [fi for fi in order if fi > p]}
-            valid = valid_cache[p]
-            out.extend((p, fi) for fi in valid[v0 : v0 + 64 * count])
+            entries = [fi for fi in order if fi > p][v0 : v0 + 64 * count]
+            out.extend((p, fi) for fi in entries)
+            if p2 != 0xFFFFFFFF:       # a second first sequence rides along on the same entries
+                assert p2 > p
+                out.extend((p2, fi) for fi in entries if fi > p2)
     return out
 
 
+@pytest.mark.parametrize("pairing", [True, False])
 @pytest.mark.parametrize("n,lo,hi", [(2, 5, 5), (65, 1, 64), (300, 6, 50), (1042, 6, 46), (3000, 10, 12)])
-def test_work_items_cover_every_pair_once(n, lo, hi):
+def test_work_items_cover_every_pair_once(n, lo, hi, pairing):
     seqs, _ = synth.generate(n, lo, hi, seed=n)
     al = sa.Aligner(device=sa.DEVICE_NONE)
     al.upload(seqs)
+    al.set_pairing(pairing)
     order = al.bucket_order().tolist()
     assert sorted(order) == list(range(n))
     for schedule in (sa.ADJACENT, sa.TRIANGULAR):
@@ -180,6 +182,9 @@ def test_work_items_cover_every_pair_once(n, lo, hi):
             else:
                 want = [(i, j) for i in range(r0, r1) for j in range(i + 1, n)]
             assert got == want
+            if schedule == sa.TRIANGULAR and n > 2:
+                has_second = any(it[5] != 0xFFFFFFFF for it in al.work_items(schedule, r0, r1).tolist())
+                assert has_second == pairing
             assert al.pair_count(schedule, r0, r1) == len(want)
             cells = sum(len(seqs[i]) * len(seqs[j]) for i, j in want)
             assert al.cell_count(schedule, r0, r1) == cells

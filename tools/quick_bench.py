@@ -7,6 +7,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 lo, hi, seed = (int(x) for x in os.environ.get('SA_LENS', '6,50,1').split(','))
 t = time.time(); seqs, _ = synth.generate(n, lo, hi, seed); print('gen', time.time()-t, flush=True)
 al = sa.Aligner(max_seq_len=max(64, hi))
+if os.environ.get("SA_PAIRING"): al.set_pairing(int(os.environ["SA_PAIRING"]))
 t = time.time(); al.upload(seqs); print('upload', time.time()-t, flush=True)
 rows = al.rows(sa.TRIANGULAR)
 pairs = al.pair_count(sa.TRIANGULAR, 0, rows); cells = al.cell_count(sa.TRIANGULAR, 0, rows)
