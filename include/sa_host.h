@@ -43,6 +43,8 @@ typedef struct {
     int32_t devices[8];
     int32_t format_threads;           /* host threads that expand and format records; 0 = min(16, cores) */
     uint64_t pairs_per_submit;        /* 0 = batch_size * 4 */
+    int32_t pairing;                  /* sa_set_pairing() of every context; default 1 */
+    int32_t reserved;
 } sa_settings;
 
 typedef struct {

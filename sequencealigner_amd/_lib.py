@@ -65,6 +65,8 @@ class Settings(C.Structure):
         ("devices", C.c_int32 * 8),
         ("format_threads", C.c_int32),
         ("pairs_per_submit", C.c_uint64),
+        ("pairing", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 

@@ -217,11 +217,15 @@ bool is_long(const sa_ctx* c) { return c->lslot > SA_LP; }
 // TRIANGULAR work of a peptide context runs on the paired kernel (two first sequences per wave)
 bool uses_pairs(const sa_ctx* c) { return c->pairing && c->table_fits_i16 && !is_long(c); }
 
-int build_items(sa_ctx* c, int schedule, uint64_t r0, uint64_t r1, std::vector<SaItem>& items) {
+// paired (in/out): the caller allows the paired kernel / the items were built for it.  A row range in which
+// fewer than half of the first sequences find a partner of their length bucket runs unpaired: a wave of
+// the paired kernel with one first sequence does half the work for the same time.
+int build_items(sa_ctx* c, int schedule, uint64_t r0, uint64_t r1, std::vector<SaItem>& items, bool& paired) {
     items.clear();
     SaItem it;
     memset(&it, 0, sizeof(it));
     if (schedule == SA_SCHEDULE_ADJACENT) {
+        paired = false;
         for (uint64_t k = r0; k < r1; k += 64) {
             it.p = (uint32_t)k;
             it.count = (uint32_t)std::min<uint64_t>(64, r1 - k);
@@ -252,16 +256,25 @@ int build_items(sa_ctx* c, int schedule, uint64_t r0, uint64_t r1, std::vector<S
             items.push_back(it);
         }
     };
-    if (!uses_pairs(c)) {
+    std::vector<std::pair<uint32_t, uint32_t>> order;
+    if (paired && uses_pairs(c)) {
+        // first sequences of the same length bucket go two by two, in file order; the valid list of the
+        // earlier one contains the later one's
+        order.reserve(r1 - r0);
+        for (uint64_t p = r0; p < r1; p++) order.push_back({(uint32_t)((c->len[p] - c->min_seq) / c->bucket_width), (uint32_t)p});
+        std::sort(order.begin(), order.end());
+        size_t partners = 0;
+        for (size_t k = 0; k + 1 < order.size();) {
+            if (order[k + 1].first == order[k].first) { partners += 2; k += 2; } else k += 1;
+        }
+        paired = 2 * partners >= order.size();
+    } else {
+        paired = false;
+    }
+    if (!paired) {
         for (uint64_t p = r0; p < r1; p++) emit(p, SA_INVALID_FI);
         return SA_OK;
     }
-    // first sequences of the same length bucket go two by two, in file order; the valid list of the
-    // earlier one contains the later one's
-    std::vector<std::pair<uint32_t, uint32_t>> order;
-    order.reserve(r1 - r0);
-    for (uint64_t p = r0; p < r1; p++) order.push_back({(uint32_t)((c->len[p] - c->min_seq) / c->bucket_width), (uint32_t)p});
-    std::sort(order.begin(), order.end());
     for (size_t k = 0; k < order.size();) {
         if (k + 1 < order.size() && order[k + 1].first == order[k].first) {
             emit(order[k].second, order[k + 1].second);
@@ -354,10 +367,11 @@ int launch_work(sa_ctx* c, Work& w, bool timed) {
 
 int prepare_work(sa_ctx* c, Work& w, int schedule, uint64_t r0, uint64_t r1, bool need_host) {
     std::vector<SaItem> items;
-    int rc = build_items(c, schedule, r0, r1, items);
+    bool paired = true;
+    int rc = build_items(c, schedule, r0, r1, items, paired);
     if (rc) return rc;
     w.schedule = schedule;
-    w.paired = schedule == SA_SCHEDULE_TRIANGULAR && uses_pairs(c);
+    w.paired = paired;
     w.first_pair = sa_pair_index(c, schedule, r0);
     w.npairs = sa_pair_count(c, schedule, r0, r1);
     w.nitems = (uint32_t)items.size();
@@ -728,7 +742,8 @@ int sa_debug_work_items(sa_ctx* c, int schedule, uint64_t r0, uint64_t r1, uint3
     if (c->nseq < 2) return SA_ERR_STATE;
     if (r1 < r0 || r1 > sa_schedule_rows(c, schedule)) return SA_ERR_ARG;
     std::vector<SaItem> items;
-    int rc = build_items(c, schedule, r0, r1, items);
+    bool paired = true;
+    int rc = build_items(c, schedule, r0, r1, items, paired);
     if (rc) return rc;
     *count = items.size();
     if (items8) {

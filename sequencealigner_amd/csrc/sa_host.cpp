@@ -261,6 +261,8 @@ void sa_settings_default(sa_settings* st) {
     for (int k = 0; k < 8; k++) st->devices[k] = k;
     st->format_threads = 0;
     st->pairs_per_submit = 0;
+    st->pairing = 1;
+    st->reserved = 0;
 }
 
 static bool parse_c_string(const char* p, char* out, size_t cap) {
@@ -366,6 +368,7 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
     if (max_len == 0 || max_len > SA_MAX_SEQ_LEN) { err = "MAX_SEQ_LEN must be between 2 and 4097"; return fail(SA_ERR_LENGTH); }
     for (int d = 0; d < ndev; d++) {
         rc = sa_init(&ctx[(size_t)d], nullptr, st->gap_penalty, max_len, st->devices[d]);
+        if (rc == SA_OK) rc = sa_set_pairing(ctx[(size_t)d], st->pairing);
         if (rc) { cleanup(); return fail(rc); }
     }
 

@@ -271,3 +271,70 @@ def test_tuner_prints_its_two_tables(tmp_path):
     assert "Pairs per submission\tTime (s)\tPairs/s" in out.stdout
     assert "Tiles per item\tWaves per CU\tKernel (ms)\tGCUPS" in out.stdout
     assert out.stdout.count("\n") >= 6 + 1 + 2 + 10
+
+
+# ---- the two TRIANGULAR peptide kernels: paired (two first sequences per wave, packed 16-bit cells,
+# the default where the table allows it) and unpaired (32-bit cells)
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,lo,hi,seed", [(700, 1, 64, 31), (900, 6, 50, 32), (257, 20, 21, 33), (130, 49, 56, 34)])
+def test_paired_and_unpaired_kernels_give_identical_records(n, lo, hi, seed):
+    """Few sequences and wide length ranges give buckets wider than one length (partners of different
+    lengths); 6..50 runs the 52-column variant, 1..64 and 49..56 the 64-column one."""
+    seqs, _ = synth.generate(n, lo, hi, seed)
+    al = sa.Aligner(max_seq_len=64)
+    al.upload(seqs)
+    paired = al.align(sa.TRIANGULAR)
+    assert any(it[5] != 0xFFFFFFFF for it in al.work_items(sa.TRIANGULAR, 0, n - 1).tolist())
+    al.set_pairing(False)
+    unpaired = al.align(sa.TRIANGULAR)
+    assert all(it[5] == 0xFFFFFFFF for it in al.work_items(sa.TRIANGULAR, 0, n - 1).tolist())
+    assert np.array_equal(paired, unpaired)
+    rng = random.Random(seed)
+    rows = [0, 1, n - 2] + [rng.randrange(n - 1) for _ in range(12)]
+    for i in rows:
+        first = al.pair_index(sa.TRIANGULAR, i)
+        pairs = [(i, j) for j in range(i + 1, n)]
+        _check_pairs(al, paired[first : first + len(pairs)], pairs)
+
+
+@pytest.mark.gpu
+def test_unpaired_kernel_csv_equals_golden_hash(tmp_path):
+    """The 32-bit TRIANGULAR kernel on the reference's data set, against the pinned hash of the
+    triangular output (the default run of the same file covers the paired kernel)."""
+    from conftest import HASHES
+    out = tmp_path / "tri.csv"
+    st = sa.default_settings()
+    al_out = sa.run_csv(os.path.join(os.path.dirname(__file__), "golden", "avpdb.csv"), str(out), sa.TRIANGULAR,
+                        settings=st, pairing=0)
+    assert al_out.pairs == 542361
+    assert sha256_file(str(out)) == HASHES["avpdb_triangular_out"]
+
+
+@pytest.mark.gpu
+def test_paired_kernel_at_the_edge_of_its_16_bit_range():
+    """S - 2*gap = 120 everywhere a residue matches and 118..120 elsewhere, 64 residues: the largest
+    values the packed cells may hold (4 * 64 * 120 + 3 < 2^15).  One step beyond, the library must
+    take the 32-bit kernel by itself."""
+    rng = random.Random(5)
+    seqs = ["".join(rng.choice(ALPHABET[:4]) for _ in range(rng.choice([64, 64, 63, 50]))) for _ in range(140)]
+    n = len(seqs)
+    for top, expect_pairs in ((112, True), (113, False)):
+        matrix = [top if a == b else top - rng.randint(0, 2) for a in range(20) for b in range(20)]
+        al = sa.Aligner(gap=-4, matrix=matrix, max_seq_len=64)
+        al.upload(seqs)
+        items = al.work_items(sa.TRIANGULAR, 0, n - 1).tolist()
+        assert any(it[5] != 0xFFFFFFFF for it in items) == expect_pairs
+        rec = al.align(sa.TRIANGULAR)
+        _check_pairs(al, rec, _tri_pairs(n, 0, n - 1), gap=-4, matrix=matrix)
+
+
+@pytest.mark.gpu
+def test_negative_shifted_scores_take_the_unpaired_kernel():
+    """A positive "gap penalty" makes S - 2*gap negative: no packed cells, same results as the checker."""
+    seqs, _ = synth.generate(200, 5, 40, 77)
+    al = sa.Aligner(gap=3, max_seq_len=64)
+    al.upload(seqs)
+    assert all(it[5] == 0xFFFFFFFF for it in al.work_items(sa.TRIANGULAR, 0, 199).tolist())
+    rec = al.align(sa.TRIANGULAR, 0, 40)
+    _check_pairs(al, rec, _tri_pairs(200, 0, 40), gap=3)
