@@ -31,6 +31,21 @@ from sequencealigner_amd import synth  # noqa: E402
 # / alignbit / packed ops, 55-64 T for plain add / sub / logic (profiles/r01_valu_issue_rates.txt).
 PEAK_TIOPS = 256 * 64 * 2.4e9 / 1e12
 OPS_PER_CELL = 5          # 3 adds + 2 max of the reference recurrence (include/seqalign.h:55-58)
+# Memory-side bytes per launch of the dominant kernel, from separate rocprofv3 --pmc passes of this
+# same command (FETCH_SIZE doubled as the gfx950 counter requires, WRITE_SIZE as read); the passes
+# and their output are kept under profiles/.  Reported as roofline.traffic when the file is there.
+PMC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")
+
+
+def measured_traffic(kernel, workload):
+    try:
+        with open(PMC_FILE) as f:
+            rec = json.load(f)
+        if rec.get("kernel") == kernel and rec.get("workload") == workload:
+            return rec.get("bytes_per_launch")
+    except (OSError, ValueError):
+        pass
+    return None
 
 WORKLOADS = {
     # name: (n, lo, hi, seed, description)
@@ -160,6 +175,10 @@ def main():
 
     if rank == 0:
         k_ms = sum(kernel_ms) / max(1, len(kernel_ms))
+        if hi > 64:
+            kernel = "sa_long_kernel<0, 2>"
+        else:
+            kernel = "sa_peptide_pair_kernel<13, 3>" if hi <= 52 else "sa_peptide_pair_kernel<16, 3>"
         achieved = my_cells * OPS_PER_CELL / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         out = {
             "metric": "GCUPS, all-vs-all Needleman-Wunsch score+traceback (aligned pairs/s alongside)",
@@ -173,7 +192,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "int32",
+            "dtype": "int32" if hi > 64 else "int16",
             "data": "synthetic",
             "config": {
                 "workload": desc,
@@ -189,12 +208,15 @@ def main():
                 "peak": round(PEAK_TIOPS, 2),
                 "unit": "TIOP/s",
                 "frac": round(achieved / PEAK_TIOPS, 4),
-                "traffic": None,
-                "kernel": "sa_long_kernel<0>" if hi > 64 else "sa_peptide_kernel<0, 3>",
+                "traffic": measured_traffic(kernel, args.workload) if world == 1 else None,
+                "kernel": kernel,
                 "kernel_ms": round(k_ms, 3),
                 "cells_per_launch": int(my_cells),
                 "ops_per_cell": OPS_PER_CELL,
-                "note": "INT32 VALU roofline (the path is not HBM- or MFMA-bound): algorithmic ops = 5 per DP cell",
+                "note": "INT32 VALU issue roofline (the path is not HBM- or MFMA-bound): algorithmic ops = 5 per DP cell "
+                        "(3 adds + 2 max of the reference recurrence); the peptide kernel packs two cells per lane "
+                        "(exact 16-bit arithmetic) and is still priced against the INT32 line; traffic = memory-side "
+                        "bytes per launch from rocprofv3 PMC passes (profiles/), null when not measured",
             },
         }
         if world == 1 and args.cpu_sample > 0:

@@ -107,7 +107,7 @@ struct sa_ctx {
     hipStream_t compute = nullptr, copy = nullptr;
     // tuning
     uint32_t tiles_per_item = 8;
-    uint32_t wg_per_cu = 12;
+    uint32_t wg_per_cu = 13;     // 12 are resident (3 waves per SIMD); one more per CU waits and fills the tail
     bool pairing = true;               // TRIANGULAR peptides: two first sequences per wave where the table allows it
     bool table_fits_i16 = false;       // 0 <= S' <= 120: packed 16-bit cells cannot overflow
     uint32_t bucket_width = 1;
