@@ -101,6 +101,46 @@ __device__ __forceinline__ void fill_row_tri_tag(const int (&IN)[SA_LP], int (&O
     SA_GROUP_TAG(15, scO, scE, e3)
 }
 
+// The same row with the table entries requested two groups ahead (three rotating buffers):
+// for kernels that run two waves per SIMD, where one group of arithmetic does not cover
+// the LDS latency.
+#define SA_GROUP_TAG2(G, CUR, FAR, ACC)                                            \
+    FAR = *reinterpret_cast<const int4*>(row_base + 4 * ((G) + 2));                \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+    SA_CELL_TAG(IN, OUT, 4 * (G) + 0, CUR.x, ACC)                                  \
+    SA_CELL_TAG(IN, OUT, 4 * (G) + 1, CUR.y, ACC)                                  \
+    SA_CELL_TAG(IN, OUT, 4 * (G) + 2, CUR.z, ACC)                                  \
+    SA_CELL_TAG(IN, OUT, 4 * (G) + 3, CUR.w, ACC)                                  \
+    if (gend == (G) + 1) return;
+
+__device__ __forceinline__ void fill_row_tri_tag2(const int (&IN)[SA_LP], int (&OUT)[SA_LP], const int gend,
+                                                  const int diag0, const int left0,
+                                                  const int32_t* __restrict__ row_base,
+                                                  const int32_t* __restrict__ next_row_base, const int4& sc_in,
+                                                  int4& sc_out, uint32_t& e0, uint32_t& e1, uint32_t& e2,
+                                                  uint32_t& e3) {
+    int4 sA = sc_in, sB, sC;
+    int zl = left0;
+    sB = *reinterpret_cast<const int4*>(row_base + 4);
+    sc_out = *reinterpret_cast<const int4*>(next_row_base);
+    SA_GROUP_TAG2(0, sA, sC, e0)
+    SA_GROUP_TAG2(1, sB, sA, e0)
+    SA_GROUP_TAG2(2, sC, sB, e0)
+    SA_GROUP_TAG2(3, sA, sC, e0)
+    SA_GROUP_TAG2(4, sB, sA, e1)
+    SA_GROUP_TAG2(5, sC, sB, e1)
+    SA_GROUP_TAG2(6, sA, sC, e1)
+    SA_GROUP_TAG2(7, sB, sA, e1)
+    SA_GROUP_TAG2(8, sC, sB, e2)
+    SA_GROUP_TAG2(9, sA, sC, e2)
+    SA_GROUP_TAG2(10, sB, sA, e2)
+    SA_GROUP_TAG2(11, sC, sB, e2)
+    SA_GROUP_TAG2(12, sA, sC, e3)
+    SA_GROUP_TAG2(13, sB, sA, e3)
+    SA_GROUP_TAG2(14, sC, sB, e3)
+    SA_GROUP_TAG2(15, sA, sC, e3)
+}
+
 // The same row with ADJACENT operands: table entries SA_TAG_TABLE(S') from an LDS copy, row
 // selected by the row residue, entry by the column residue (a4 = 4 * residue code).
 __device__ __forceinline__ void fill_row_adj_tag(const int (&IN)[SA_LP], int (&OUT)[SA_LP], const int gend,

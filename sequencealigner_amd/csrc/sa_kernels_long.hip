@@ -28,6 +28,11 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_kernel(const SaPep
     const uint32_t strips_cap = P.lslot >> 6;
     uint32_t* const dirs = P.spill + (size_t)blockIdx.x * strips_cap * rows_cap * 256;
     int32_t* const bcol = P.bcol + (size_t)blockIdx.x * 2 * rows_cap * 64;
+    // optional phase timers: 0 fetch, 2 operands, 3 fill, 4 traceback + record
+    const bool timed = P.phase_cycles != nullptr;
+    unsigned long long tph[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long tmark = timed ? __builtin_amdgcn_s_memtime() : 0;
+#define SA_PHASE(k) do { if (timed) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tph[k] += t_ - tmark; tmark = t_; } } while (0)
 
     if (MODE == SA_MODE_ADJ) {
         for (int e = lane; e < 20 * 32; e += 64) {
@@ -43,6 +48,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_kernel(const SaPep
         it = __builtin_amdgcn_readfirstlane(it);
         if (it >= P.nitems) break;
         const SaItem item = P.items[it];
+        SA_PHASE(0);
 
         int lenp_u = 0;
         uint8_t* out_row;
@@ -66,6 +72,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_kernel(const SaPep
             const uint8_t* brow;          // row residue r of this lane at brow[r * bstep]
             size_t bstep;
             const uint8_t* acol;          // column residues of this lane's sequence 1
+            const uint8_t* bslot;         // sequence 2 as one padded slot of lslot bytes
             if (MODE == SA_MODE_TRI) {
                 const uint32_t vbase = item.v0 + task * 64;
                 const uint32_t vl = vbase + lane;
@@ -88,6 +95,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_kernel(const SaPep
                 rel = fiq - item.p - 1;
                 brow = P.codes_t + sidx;
                 bstep = P.npad;
+                bslot = P.codes_fo + (size_t)fiq * P.lslot;
                 acol = P.codes_fo + (size_t)item.p * P.lslot;
             } else {
                 active = (uint32_t)lane < item.count;
@@ -99,12 +107,14 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_kernel(const SaPep
                 rel = lane;
                 acol = P.codes_fo + (size_t)s1 * P.lslot;
                 brow = P.codes_fo + (size_t)s2 * P.lslot;
+                bslot = brow;
                 bstep = 1;
             }
             maxlen = __builtin_amdgcn_readfirstlane(wave_max(lenq));
             const int nstrips = (maxlenp + 63) >> 6;
             const int gend_last = ((maxlenp - 64 * (nstrips - 1)) + 3) >> 2;
             const int last_row = (int)rows_cap - 1;
+            SA_PHASE(2);
 
             // -------------------------------------------------------------- fill
             int dfinal = 0;
@@ -136,8 +146,9 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_kernel(const SaPep
 #pragma unroll
                 for (int c = 0; c < SA_LP; c++) { R[c] = 1; Q[c] = 1; }     // border row: 4*0 + 1
                 uint32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;
-                const int32_t* bin = bcol + (size_t)(s & 1) * rows_cap * 64 + lane;
-                int32_t* bout = bcol + (size_t)((s + 1) & 1) * rows_cap * 64 + lane;
+                // border column: four rows per lane and 16 bytes, [strip parity][row / 4][lane][row % 4]
+                const int4* bin = reinterpret_cast<const int4*>(bcol + (size_t)(s & 1) * rows_cap * 64) + lane;
+                int4* bout = reinterpret_cast<int4*>(bcol + (size_t)((s + 1) & 1) * rows_cap * 64) + lane;
                 uint32_t* drow = dirs + ((size_t)s * rows_cap * 64 + lane) * 4;
                 const bool first_strip = s == 0, more_strips = s + 1 < nstrips;
                 // the last dword a row writes took 4*gend - 16*(wl) cells: its first column is moved down to bit 0
@@ -145,38 +156,54 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_kernel(const SaPep
                 const int lsh = 32 - 2 * (4 * gend - 16 * wl);
                 const int sh0 = wl == 0 ? lsh : 0, sh1 = wl == 1 ? lsh : 0, sh2 = wl == 2 ? lsh : 0, sh3 = wl == 3 ? lsh : 0;
 
-                auto residue = [&](int r) -> int { return (int)brow[(size_t)min(r, last_row) * bstep]; };
-                // last column of the previous strip in bank form (4*D + 1); 1 on the matrix border
-                auto border = [&](int r) -> int { return first_strip ? 1 : bin[(size_t)min(r, last_row) * 64]; };
-                int b0 = residue(0), b1 = residue(1);
-                int l0 = border(0), l1 = border(1);
+                // Rows go four at a time.  The four row residues (one dword of sequence 2's slot) and the four
+                // border values (last column of the previous strip in bank form 4*D + 1; 1 on the matrix border)
+                // of the next block are requested at the top of a block, four rows of arithmetic before they
+                // are needed, and the block's own last-column values leave in one 16-byte store.  The direction
+                // rows are stored by every lane, also by lanes whose sequence 2 has ended (their rows are never
+                // read): the number of stores between a request and its use is then the same for every wave, and
+                // the wait before the use can leave those stores in flight.
+                auto residues4 = [&](int r) -> uint32_t {
+                    return *reinterpret_cast<const uint32_t*>(bslot + min(r, last_row - 3));
+                };
+                auto border4 = [&](int r) -> int4 {
+                    return first_strip ? make_int4(1, 1, 1, 1) : bin[(size_t)(min(r, last_row - 3) >> 2) * 64];
+                };
+                auto prow = [&](uint32_t b) -> const int32_t* {
+                    return (MODE == SA_MODE_TRI) ? prof + b * SA_PROF_STRIDE : prof + (b < 20 ? b : 0) * 32;
+                };
+                uint32_t bres = residues4(0);
+                int4 bord = border4(0);
                 int dprev = 1;                                   // border value of the previous row = diag of column 0
                 int4 sc0 = make_int4(0, 0, 0, 0), sc1 = sc0;
-                if (MODE == SA_MODE_TRI) sc0 = *reinterpret_cast<const int4*>(prof + b0 * SA_PROF_STRIDE);
-                for (int r = 0; r < maxlen; r += 2) {
-                    const int b2 = residue(r + 2), b3 = residue(r + 3);
-                    const int l2 = border(r + 2), l3 = border(r + 3);
-                    if (r < lenq) {
-                        if (MODE == SA_MODE_TRI)
-                            fill_row_tri_tag(R, Q, gend, dprev, l0 - 1, prof + b0 * SA_PROF_STRIDE, prof + b1 * SA_PROF_STRIDE, sc0, sc1,
-                                             e0, e1, e2, e3);
-                        else
-                            fill_row_adj_tag(R, Q, gend, dprev, l0 - 1, prof + (b0 < 20 ? b0 : 0) * 32, a4, e0, e1, e2, e3);
-                        *reinterpret_cast<uint4*>(drow + (size_t)r * 256) = make_uint4(e0 >> sh0, e1 >> sh1, e2 >> sh2, e3 >> sh3);
-                        if (more_strips) bout[(size_t)r * 64] = Q[SA_LP - 1];
-                    }
-                    if (r + 1 < lenq) {
-                        if (MODE == SA_MODE_TRI)
-                            fill_row_tri_tag(Q, R, gend, l0, l1 - 1, prof + b1 * SA_PROF_STRIDE, prof + b2 * SA_PROF_STRIDE, sc1, sc0,
-                                             e0, e1, e2, e3);
-                        else
-                            fill_row_adj_tag(Q, R, gend, l0, l1 - 1, prof + (b1 < 20 ? b1 : 0) * 32, a4, e0, e1, e2, e3);
-                        *reinterpret_cast<uint4*>(drow + (size_t)(r + 1) * 256) = make_uint4(e0 >> sh0, e1 >> sh1, e2 >> sh2, e3 >> sh3);
-                        if (more_strips) bout[(size_t)(r + 1) * 64] = R[SA_LP - 1];
-                    }
-                    dprev = l1;
-                    b0 = b2; b1 = b3; l0 = l2; l1 = l3;
+                if (MODE == SA_MODE_TRI) sc0 = *reinterpret_cast<const int4*>(prof + (bres & 0xff) * SA_PROF_STRIDE);
+#define SA_LONG_ROW(IN, OUT, RR, DIAG0, LEFTY, B, BNEXT, SCI, SCO)                                                              \
+    if ((RR) < lenq) {                                                                                                           \
+        if (MODE == SA_MODE_TRI)                                                                                                 \
+            fill_row_tri_tag2(IN, OUT, gend, DIAG0, (LEFTY) - 1, prow(B), prow(BNEXT), SCI, SCO, e0, e1, e2, e3);                \
+        else                                                                                                                     \
+            fill_row_adj_tag(IN, OUT, gend, DIAG0, (LEFTY) - 1, prow(B), a4, e0, e1, e2, e3);                                   \
+    }                                                                                                                            \
+    *reinterpret_cast<uint4*>(drow + (size_t)(RR) * 256) = make_uint4(e0 >> sh0, e1 >> sh1, e2 >> sh2, e3 >> sh3);
+                for (int r = 0; r < maxlen; r += 4) {
+                    const uint32_t nres = residues4(r + 4);
+                    const int4 nbord = border4(r + 4);
+                    const uint32_t rb0 = bres & 0xff, rb1 = (bres >> 8) & 0xff, rb2 = (bres >> 16) & 0xff, rb3 = bres >> 24;
+                    int4 lastc;
+                    SA_LONG_ROW(R, Q, r, dprev, bord.x, rb0, rb1, sc0, sc1)
+                    lastc.x = Q[SA_LP - 1];
+                    SA_LONG_ROW(Q, R, r + 1, bord.x, bord.y, rb1, rb2, sc1, sc0)
+                    lastc.y = R[SA_LP - 1];
+                    SA_LONG_ROW(R, Q, r + 2, bord.y, bord.z, rb2, rb3, sc0, sc1)
+                    lastc.z = Q[SA_LP - 1];
+                    SA_LONG_ROW(Q, R, r + 3, bord.z, bord.w, rb3, (nres & 0xff), sc1, sc0)
+                    lastc.w = R[SA_LP - 1];
+                    if (more_strips) bout[(size_t)(r >> 2) * 64] = lastc;
+                    dprev = bord.w;
+                    bres = nres;
+                    bord = nbord;
                 }
+#undef SA_LONG_ROW
                 // the score sits in the strip that holds this lane's last column
                 if (((lenp - 1) >> 6) == s) {
                     const int col = (lenp - 1) & 63;
@@ -192,6 +219,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_kernel(const SaPep
                 __syncthreads();   // border column and direction rows are complete before anyone reads them
             }
             const int score = (dfinal >> 2) + (lenp + lenq) * P.gap;      // banks hold 4*D + 1
+            SA_PHASE(3);
 
             // --------------------------------------------------------- traceback
             uint8_t* rec = out_row + (size_t)rel * P.stride;
@@ -240,8 +268,14 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_kernel(const SaPep
                     *reinterpret_cast<uint4*>(rec + o) = make_uint4(0, 0, 0, 0);
             }
             __syncthreads();
+            SA_PHASE(4);
         }
     }
+    if (timed && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) P.phase_cycles[(size_t)blockIdx.x * 8 + k] = tph[k];
+    }
+#undef SA_PHASE
 }
 
 extern "C" void sa_launch_long(int mode, const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream) {
