@@ -130,6 +130,9 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
         P.spill + (size_t)blockIdx.x * P.spill_rows * 256, 0, P.spill_rows * 1024, SA_BUFFER_FLAGS);
     const __amdgpu_buffer_rsrc_t codes_t = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint8_t*>(P.codes_t), 0, SA_LP * P.npad, SA_BUFFER_FLAGS);
+    // the same descriptor as four scalar words, for the hand-written residue requests
+    const uint64_t ct_addr = reinterpret_cast<uint64_t>(P.codes_t);
+    const sa_u32x4 codes_t_words = {(uint32_t)ct_addr, (uint32_t)(ct_addr >> 32) & 0xffffu, SA_LP * P.npad, SA_BUFFER_FLAGS};
     const uint32_t cpr = P.stride >> 4;   // 16-byte chunks per record
     const bool timed = P.phase_cycles != nullptr;
     unsigned long long tph[6] = {0, 0, 0, 0, 0, 0};
@@ -203,8 +206,15 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
 #pragma unroll
             for (int w = 0; w < NACC; w++) e[w] = 0;
 
-            auto residue = [&](int r) -> int {
-                return (int)__builtin_amdgcn_raw_buffer_load_b8(codes_t, sidx, min(r, SA_LP - 1) * (int)P.npad, 0);
+            // Row residue r of the lane's second sequence.  The request is written as an instruction of its own,
+            // outside the compiler's bookkeeping of outstanding memory operations: the compiler would wait for
+            // *everything* in flight before the first use, direction stores included; here the wait is counted by
+            // hand (see the end of the row loop).
+            auto residue = [&](int r) -> uint32_t {
+                uint32_t v;
+                const int soff = min(r, SA_LP - 1) * (int)P.npad;
+                asm volatile("buffer_load_ubyte %0, %1, %2, %3 offen" : "=v"(v) : "v"(sidx), "s"(codes_t_words), "s"(soff) : "memory");
+                return v;
             };
             const int dir_lane = lane * wpr * 4;      // byte offset of this lane inside a direction row
             const int half_off = SA_LP * 256 * wpr;   // byte offset of the high halves' rows
@@ -241,24 +251,32 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
                 }
             };
 
-            int b0 = residue(0), b1 = residue(1);
-            int4 sc0 = *reinterpret_cast<const int4*>(prof + b0 * SA_PROF_STRIDE);
+            // Profile rows (as dword offsets) of the two rows to come.  The residues of rows r+2, r+3 are requested
+            // at the top of an iteration and turned into offsets at its end, after the four direction stores, so
+            // that the wait for them stands where those stores may stay in flight.
+            const uint32_t ra = residue(0), rb = residue(1);
+            uint32_t o0, o1;
+            asm volatile("s_waitcnt vmcnt(0)\n\tv_mul_u32_u24 %0, %2, %4\n\tv_mul_u32_u24 %1, %3, %4"
+                         : "=&v"(o0), "=&v"(o1) : "v"(ra), "v"(rb), "s"(SA_PROF_STRIDE));
+            int4 sc0 = *reinterpret_cast<const int4*>(prof + o0);
             for (int r = 0; r < maxlen; r += 2) {
-                // residues two rows ahead: their latency is covered by two rows of arithmetic
-                const int b2 = residue(r + 2), b3 = residue(r + 3);
+                const uint32_t b2 = residue(r + 2), b3 = residue(r + 3);
                 // the row's end tests compare this copy of gend where they stand: hoisted out of the loop they
                 // would each hold a pair of scalar registers, more than there are
                 int gr = gend;
                 asm volatile("" : "+s"(gr));
-                if (r < lenq) {
-                    fill_row_pair<NG>(R, Q, gr, prof + b0 * SA_PROF_STRIDE, prof + b1 * SA_PROF_STRIDE, sc0, sc0, e);
-                    store_dirs(r, gr);
-                }
-                if (r + 1 < lenq) {
-                    fill_row_pair<NG>(Q, R, gr, prof + b1 * SA_PROF_STRIDE, prof + b2 * SA_PROF_STRIDE, sc0, sc0, e);
-                    store_dirs(r + 1, gr);
-                }
-                b0 = b2; b1 = b3;
+                // every lane stores its direction row, also lanes whose sequence 2 has ended (those rows are never
+                // read): every wave then issues exactly four stores per iteration
+                if (r < lenq) fill_row_pair<NG>(R, Q, gr, prof + o0, prof + o1, sc0, sc0, e);
+                store_dirs(r, gr);
+                // Memory operations finish in the order they were issued: with at most the four direction stores
+                // of this iteration still in flight, the two residues requested before them have arrived.
+                uint32_t o2, o3;
+                asm volatile("s_waitcnt vmcnt(2)\n\tv_mul_u32_u24 %0, %2, %4\n\tv_mul_u32_u24 %1, %3, %4"
+                             : "=&v"(o2), "=&v"(o3) : "v"(b2), "v"(b3), "s"(SA_PROF_STRIDE));
+                if (r + 1 < lenq) fill_row_pair<NG>(Q, R, gr, prof + o1, prof + o2, sc0, sc0, e);
+                store_dirs(r + 1, gr);
+                o0 = o2; o1 = o3;
             }
             // banks hold 4*D + 2 per half
             const uint32_t y1q = pick_packed<NC>(Q, lenp1 - 1), y1r = pick_packed<NC>(R, lenp1 - 1);
