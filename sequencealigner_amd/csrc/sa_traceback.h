@@ -50,7 +50,9 @@ __device__ __forceinline__ void traceback(const int lane, const int maxlen, cons
                                           const uint32_t (&bw)[16], const uint8_t* __restrict__ brow,
                                           const uint8_t* __restrict__ acol, const uint64_t* __restrict__ emask,
                                           uint32_t* __restrict__ stage_rec, int& matches_out, int& gaps_out) {
-    int j = lenp, matches = 0, gaps = 0;
+    // j2 = twice the number of columns of sequence 1 still to the left of the walk: the tags are two bits
+    // wide, so shift amounts, run lengths and the output byte (run * 2 + up) all come in this unit
+    int j2 = 2 * lenp, matches = 0, gaps = 0;
     const int lane_off = lane * W * 4;
 
     // Nothing loaded here is used before process().  Row indices past the end of
@@ -91,53 +93,52 @@ __device__ __forceinline__ void traceback(const int lane, const int maxlen, cons
                 // DIAG does).  Branch-free per lane: with j == 0 the window is meaningless, the run
                 // is cut to 0 and the move is UP (left border).
                 int L;
+                const uint32_t sh = 0u - (uint32_t)j2;       // (32 or 64 - j2) modulo the width of the shift
                 if (REV) {
                     if (W == 1) {
-                        const uint32_t x = ck.d[k].x >> ((32 - 2 * j) & 31);
+                        const uint32_t x = ck.d[k].x >> (sh & 31);
                         L = x ? __builtin_ctz(x) : 32;
                     } else if (W == 2) {
                         const uint64_t v = ((uint64_t)ck.d[k].x << 32) | ck.d[k].y;
-                        const uint64_t x = v >> ((64 - 2 * j) & 63);
+                        const uint64_t x = v >> (sh & 63);
                         L = x ? __builtin_ctzll(x) : 64;
                     } else {
                         const uint64_t v0 = ((uint64_t)ck.d[k].x << 32) | ck.d[k].y;
                         const uint64_t v1 = ((uint64_t)ck.d[k].z << 32) | ck.d[k].w;
-                        const bool upper = j > 32;
-                        const int jj = upper ? j - 32 : j;
-                        const uint64_t x = (upper ? v1 : v0) >> ((64 - 2 * jj) & 63);
+                        const bool upper = j2 > 64;
+                        const uint64_t x = (upper ? v1 : v0) >> (sh & 63);
                         const int l0 = v0 ? __builtin_ctzll(v0) : 64;
-                        L = x ? __builtin_ctzll(x) : (upper ? 2 * jj + l0 : 64);
+                        L = x ? __builtin_ctzll(x) : (upper ? j2 - 64 + l0 : 64);
                     }
                 } else if (W == 1) {
-                    const uint32_t x = ck.d[k].x << ((32 - 2 * j) & 31);
+                    const uint32_t x = ck.d[k].x << (sh & 31);
                     L = x ? __builtin_clz(x) : 32;
                 } else if (W == 2) {
                     const uint64_t v = ((uint64_t)ck.d[k].y << 32) | ck.d[k].x;
-                    const uint64_t x = v << ((64 - 2 * j) & 63);
+                    const uint64_t x = v << (sh & 63);
                     L = x ? __builtin_clzll(x) : 64;
                 } else {
                     // columns 32..63 in one 64-bit half, 0..31 in the other; a run that starts in the
                     // upper half and finds nothing there goes on from column 31
                     const uint64_t v0 = ((uint64_t)ck.d[k].y << 32) | ck.d[k].x;
                     const uint64_t v1 = ((uint64_t)ck.d[k].w << 32) | ck.d[k].z;
-                    const bool upper = j > 32;
-                    const int jj = upper ? j - 32 : j;
-                    const uint64_t x = (upper ? v1 : v0) << ((64 - 2 * jj) & 63);
+                    const bool upper = j2 > 64;
+                    const uint64_t x = (upper ? v1 : v0) << (sh & 63);
                     const int l0 = v0 ? __builtin_clzll(v0) : 64;
-                    L = x ? __builtin_clzll(x) : (upper ? 2 * jj + l0 : 64);
+                    L = x ? __builtin_clzll(x) : (upper ? j2 - 64 + l0 : 64);
                 }
-                const int run = min(L >> 1, j);
-                j -= run;
-                const int t = (j > 0) ? (L & 1) : 1;                       // 0 = DIAG, 1 = UP (left border: UP)
-                const int c1 = (j - 1) & 63;
+                const int run2 = min(L & ~1, j2);                          // twice the run of LEFT moves
+                j2 -= run2;
+                const int t = (j2 > 0) ? (L & 1) : 1;                      // 0 = DIAG, 1 = UP (left border: UP)
+                const int c1 = ((j2 >> 1) - 1) & 63;
                 const int dg = t ^ 1;
                 int eq;
                 if (MODE == SA_MODE_TRI) eq = (W > 2) ? (int)((e[k] >> c1) & 1) : (int)(((uint32_t)e[k] >> (c1 & 31)) & 1);
                 else eq = (t == 0 && (uint32_t)acol[c1] == ((b4 >> (8 * k)) & 0xff)) ? 1 : 0;
                 matches += eq & dg;
-                j -= dg;
+                j2 -= 2 * dg;
                 gaps += t;
-                packed |= (uint32_t)(run * 2 + t) << (8 * k);
+                packed |= (uint32_t)(run2 + t) << (8 * k);
             }
         }
         stage_rec[2 + ch] = packed;
