@@ -235,7 +235,8 @@ int build_items(sa_ctx* c, int schedule, uint64_t r0, uint64_t r1, std::vector<S
     }
     int rc = ensure_triangular(c);
     if (rc) return rc;
-    const uint32_t nb = c->nb, per = std::max(1u, c->tiles_per_item);
+    // long sequences: one 64-pair tile is already milliseconds of work, and few items per workgroup leave a long tail
+    const uint32_t nb = c->nb, per = is_long(c) ? 1u : std::max(1u, c->tiles_per_item);
     // items of first sequence p (and, in the paired kernel, of a second one p2 > p that rides along)
     auto emit = [&](uint64_t p, uint32_t p2) {
         const uint32_t nvalid = (uint32_t)(c->nseq - 1 - p);
@@ -273,17 +274,26 @@ int build_items(sa_ctx* c, int schedule, uint64_t r0, uint64_t r1, std::vector<S
     }
     if (!paired) {
         for (uint64_t p = r0; p < r1; p++) emit(p, SA_INVALID_FI);
+        // long sequences: items differ a lot in work (first sequences of 300 and of 1000 residues); the
+        // longest go first so that the tail of the launch is made of short ones
+        if (is_long(c))
+            std::stable_sort(items.begin(), items.end(),
+                             [c](const SaItem& a, const SaItem& b) { return c->len[a.p] > c->len[b.p]; });
         return SA_OK;
     }
+    // the partners are found in ascending bucket order; the items go out longest bucket first, so that the
+    // tail of the launch is made of short first sequences
+    std::vector<std::pair<uint32_t, uint32_t>> duo;      // (p1, p2 or none), ascending buckets
     for (size_t k = 0; k < order.size();) {
         if (k + 1 < order.size() && order[k + 1].first == order[k].first) {
-            emit(order[k].second, order[k + 1].second);
+            duo.push_back({order[k].second, order[k + 1].second});
             k += 2;
         } else {
-            emit(order[k].second, SA_INVALID_FI);
+            duo.push_back({order[k].second, SA_INVALID_FI});
             k += 1;
         }
     }
+    for (size_t k = duo.size(); k-- > 0;) emit(duo[k].first, duo[k].second);
     return SA_OK;
 }
 
