@@ -364,7 +364,7 @@ int launch_work(sa_ctx* c, Work& w, bool timed) {
     P.lslot = c->lslot;
     P.bcol = (int32_t*)c->d_bcol.p;
     if (is_long(c))
-        sa_launch_long(w.schedule == SA_SCHEDULE_TRIANGULAR ? 0 : 1, &P, grid, SA_LDS_PROF_BYTES + 64, c->compute);   // the row reads table entries two groups ahead, up to 16 bytes past the last profile row
+        sa_launch_long(w.schedule == SA_SCHEDULE_TRIANGULAR ? 0 : 1, &P, grid, SA_LDS_PROF_BYTES + 64 + c->lslot, c->compute);   // + 64: the row reads table entries two groups ahead, up to 16 bytes past the last profile row; + lslot: copy of the shared first sequence
     else if (w.schedule == SA_SCHEDULE_TRIANGULAR && w.paired)
         sa_launch_peptide_pair(c->max_seq <= 52 ? 13 : 16, &P, grid, SA_LDS_FIXED_BYTES + SA_LDS_EMASK_BYTES, c->compute);
     else

@@ -23,6 +23,7 @@ template <int MODE, int WAVES_PER_SIMD>
 __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_kernel(const SaPepParams P) {
     extern __shared__ __align__(16) uint8_t smem[];
     int32_t* const prof = reinterpret_cast<int32_t*>(smem);
+    uint8_t* const pseq = smem + SA_LDS_PROF_BYTES + 64;      // TRIANGULAR: the shared first sequence, lslot bytes
     const int lane = threadIdx.x;
     const uint32_t rows_cap = P.lslot;
     const uint32_t strips_cap = P.lslot >> 6;
@@ -55,6 +56,10 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_kernel(const SaPep
         uint32_t ntasks;
         if (MODE == SA_MODE_TRI) {
             lenp_u = P.len_fo[item.p];
+            __syncthreads();      // the previous item's walks are done with the copy
+            for (uint32_t o = lane * 16; o < P.lslot; o += 64 * 16)
+                *reinterpret_cast<uint4*>(pseq + o) = *reinterpret_cast<const uint4*>(P.codes_fo + (size_t)item.p * P.lslot + o);
+            __syncthreads();
             const uint64_t n = P.nseq;
             const uint64_t row_start = (uint64_t)item.p * (2 * n - item.p - 1) / 2;
             out_row = P.out + (row_start - P.out_base_pair) * P.stride;
@@ -222,20 +227,45 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_kernel(const SaPep
             SA_PHASE(3);
 
             // --------------------------------------------------------- traceback
+            // One row per step, bottom row first, eight rows per 16-byte piece of the record.  A row needs the
+            // 16 bytes of direction tags of the strip its column is in, which depends on where the walk stands.
+            // TRIANGULAR: the tags are requested eight rows ahead for the strip the walk is in at that moment
+            // (it changes strip once in 64 columns; a wrong guess is loaded again when it is used), the eight
+            // row residues come as two dwords a piece ahead, and the shared first sequence is read from LDS.
             uint8_t* rec = out_row + (size_t)rel * P.stride;
             int j = lenp, matches = 0, gaps = 0;
-            for (int ch = (maxlen - 1) >> 3; ch >= 0; --ch) {
+            auto load_tags = [&](int sj, int r) -> uint4 {
+                return *reinterpret_cast<const uint4*>(dirs + (((size_t)sj * rows_cap + min(r, last_row)) * 64 + lane) * 4);
+            };
+            constexpr bool AHEAD = MODE == SA_MODE_TRI;
+            uint4 ring[AHEAD ? 8 : 1];
+            int ring_s[AHEAD ? 8 : 1];
+            uint2 resq = make_uint2(0, 0);
+            const int ch0 = (maxlen - 1) >> 3;
+            if (AHEAD) {
+                const int s0 = (lenp - 1) >> 6;
+#pragma unroll
+                for (int k = 0; k < 8; k++) { ring[k] = load_tags(s0, 8 * ch0 + k); ring_s[k] = s0; }
+                resq = *reinterpret_cast<const uint2*>(bslot + min(8 * ch0, last_row - 7));
+            }
+            for (int ch = ch0; ch >= 0; --ch) {
                 uint32_t w[4] = {0, 0, 0, 0};
+                const uint2 res = resq;
+                if (AHEAD && ch > 0) resq = *reinterpret_cast<const uint2*>(bslot + 8 * (ch - 1));
 #pragma unroll
                 for (int k = 7; k >= 0; k--) {
                     const int r = 8 * ch + k;
                     if (r < lenq) {
                         int run_total = 0, t = 1;
+                        bool first = true;
                         while (j > 0) {
                             // tags of the strip column j-1 is in; L = leading zeros from that column down =
                             // 2 * (LEFT moves) + (1 if an UP ends the run, 0 if a DIAG does)
                             const int sj = (j - 1) >> 6, jl = ((j - 1) & 63) + 1;
-                            const uint4 d = *reinterpret_cast<const uint4*>(dirs + (((size_t)sj * rows_cap + r) * 64 + lane) * 4);
+                            uint4 d;
+                            if (AHEAD && first && ring_s[AHEAD ? k : 0] == sj) d = ring[AHEAD ? k : 0];
+                            else d = load_tags(sj, r);
+                            first = false;
                             const uint64_t v0 = ((uint64_t)d.y << 32) | d.x;
                             const uint64_t v1 = ((uint64_t)d.w << 32) | d.z;
                             const bool upper = jl > 32;
@@ -251,11 +281,25 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_kernel(const SaPep
                             break;
                         }
                         if (t == 0) {
-                            matches += (acol[j - 1] == brow[(size_t)r * bstep]) ? 1 : 0;
+                            uint32_t a, b;
+                            if (AHEAD) {
+                                a = pseq[j - 1];
+                                b = ((k < 4 ? res.x : res.y) >> (8 * (k & 3))) & 0xff;
+                            } else {
+                                a = acol[j - 1];
+                                b = brow[(size_t)r * bstep];
+                            }
+                            matches += (a == b) ? 1 : 0;
                             j--;
                         }
                         gaps += t;
                         w[k >> 1] |= (uint32_t)(run_total * 2 + t) << (16 * (k & 1));
+                    }
+                    if (AHEAD && ch > 0) {
+                        // the same row of the next piece, for the strip the walk is in now
+                        const int sn = (max(j, 1) - 1) >> 6;
+                        ring[AHEAD ? k : 0] = load_tags(sn, r - 8);
+                        ring_s[AHEAD ? k : 0] = sn;
                     }
                 }
                 if (active)
