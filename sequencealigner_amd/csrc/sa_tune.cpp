@@ -69,7 +69,7 @@ int main(int argc, char** argv) {
     const double cells = (double)sa_cell_count(ctx, SA_SCHEDULE_TRIANGULAR, 0, rows);
     printf("\nTiles per item\tWaves per CU\tKernel (ms)\tGCUPS\n");
     const uint32_t tiles[] = {2, 4, 8, 16, 32};
-    const uint32_t waves[] = {8, 12};
+    const uint32_t waves[] = {8, 12, 13};
     for (uint32_t w : waves)
         for (uint32_t t : tiles) {
             sa_set_tuning(ctx, t, w);
