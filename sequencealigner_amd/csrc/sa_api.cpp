@@ -21,6 +21,7 @@ extern "C" void sa_launch_peptide(int mode, int waves_per_simd, const SaPepParam
 extern "C" void sa_launch_pack_slots(const uint8_t* codes, const uint64_t* offs, const uint32_t* lens, uint64_t nseq,
                                      uint64_t nslots, uint32_t lslot, uint8_t* slots, uint16_t* len16, hipStream_t stream);
 extern "C" void sa_launch_peptide_pair(int ng, const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream);
+extern "C" void sa_launch_long_pair(const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream);
 extern "C" void sa_launch_long(int mode, const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream);
 
 namespace {
@@ -110,6 +111,7 @@ struct sa_ctx {
     uint32_t wg_per_cu = 13;     // 12 are resident (3 waves per SIMD); one more per CU waits and fills the tail
     bool pairing = true;               // TRIANGULAR peptides: two first sequences per wave where the table allows it
     bool table_fits_i16 = false;       // 0 <= S' <= 120: packed 16-bit cells cannot overflow
+    bool table_fits_long = false;      // 0 <= S' <= 48: the same for the long-sequence paired kernel
     uint32_t bucket_width = 1;
     // sequences (host mirror)
     uint64_t nseq = 0;
@@ -143,13 +145,16 @@ uint64_t tri_row_start(uint64_t n, uint64_t i) { return i * (2 * n - i - 1) / 2;
 
 // The paired kernel keeps 4*D + 3 in 16 bits with D <= 64 * max S' (S' = S - 2*gap, 64 = longest
 // peptide) and adds table entries as unsigned halves: it needs 0 <= S' <= 120.
-bool table_fits_i16(const int32_t* S, int32_t gap) {
+// The long-sequence paired kernel keeps D minus a per-lane base that follows the strip's border column
+// and is moved every 64 rows: a register holds at most 4 * 129 * max S' + 3, which needs S' <= 48.
+bool table_within(const int32_t* S, int32_t gap, int64_t top) {
     for (int k = 0; k < 400; k++) {
         const int64_t sp = (int64_t)S[k] - 2 * (int64_t)gap;
-        if (sp < 0 || sp > 120) return false;
+        if (sp < 0 || sp > top) return false;
     }
     return true;
 }
+bool table_fits_i16(const int32_t* S, int32_t gap) { return table_within(S, gap, 120); }
 
 // Bucket order of the sequences and the cursor table (see sa_device.h); TRIANGULAR only.
 int ensure_triangular(sa_ctx* c) {
@@ -215,7 +220,7 @@ int ensure_triangular(sa_ctx* c) {
 bool is_long(const sa_ctx* c) { return c->lslot > SA_LP; }
 
 // TRIANGULAR work of a peptide context runs on the paired kernel (two first sequences per wave)
-bool uses_pairs(const sa_ctx* c) { return c->pairing && c->table_fits_i16 && !is_long(c); }
+bool uses_pairs(const sa_ctx* c) { return c->pairing && (is_long(c) ? c->table_fits_long : c->table_fits_i16); }
 
 // paired (in/out): the caller allows the paired kernel / the items were built for it.  A row range in which
 // fewer than half of the first sequences find a partner of their length bucket runs unpaired: a wave of
@@ -300,14 +305,14 @@ int build_items(sa_ctx* c, int schedule, uint64_t r0, uint64_t r1, std::vector<S
 // global scratch of one workgroup: direction rows (and, for long sequences, the strip border columns)
 size_t spill_bytes_per_wg(const sa_ctx* c) {
     if (!is_long(c)) return (size_t)2 * SA_LP * 1024;      // two sets of direction rows for the paired kernel
-    return (size_t)(c->lslot / 64) * c->lslot * 1024;
+    return (size_t)2 * (c->lslot / 64) * c->lslot * 1024;       // strips x rows x 1 KiB, for each half of the paired kernel
 }
 
 uint32_t grid_for(const sa_ctx* c) {
     if (is_long(c)) {
         // two waves per SIMD (a third one spills registers inside the row loop: measured 1.8 vs 3.0 TCUPS);
-        // the direction area of a workgroup is large, keep the total under 32 GiB
-        const uint64_t budget = 32ull << 30;
+        // the direction area of a workgroup is large, keep the total under 96 GiB of the 288
+        const uint64_t budget = 96ull << 30;
         uint64_t g = std::min<uint64_t>((uint64_t)c->ncu * 8, budget / spill_bytes_per_wg(c));
         return (uint32_t)std::max<uint64_t>(1, g);
     }
@@ -320,7 +325,7 @@ int ensure_spill(sa_ctx* c, uint32_t grid) {
     if (grid <= c->spill_grid) return SA_OK;
     int rc = c->d_spill.reserve((size_t)grid * spill_bytes_per_wg(c));
     if (rc) return rc;
-    if (is_long(c) && (rc = c->d_bcol.reserve((size_t)grid * 2 * c->lslot * 256))) return rc;
+    if (is_long(c) && (rc = c->d_bcol.reserve((size_t)grid * 4 * c->lslot * 256))) return rc;
     c->spill_grid = grid;
     return SA_OK;
 }
@@ -363,7 +368,10 @@ int launch_work(sa_ctx* c, Work& w, bool timed) {
     if (timed) SA_HIP_TRY(hipEventRecord(w.t0, c->compute));
     P.lslot = c->lslot;
     P.bcol = (int32_t*)c->d_bcol.p;
-    if (is_long(c))
+    if (is_long(c) && w.schedule == SA_SCHEDULE_TRIANGULAR && w.paired)
+        // + 64: rows read table entries two groups ahead, up to 16 bytes past the last profile row; + 2 lslot: the two first sequences
+        sa_launch_long_pair(&P, grid, SA_LDS_PROF_BYTES + 64 + 2 * c->lslot, c->compute);
+    else if (is_long(c))
         sa_launch_long(w.schedule == SA_SCHEDULE_TRIANGULAR ? 0 : 1, &P, grid, SA_LDS_PROF_BYTES + 64 + c->lslot, c->compute);   // + 64: the row reads table entries two groups ahead, up to 16 bytes past the last profile row; + lslot: copy of the shared first sequence
     else if (w.schedule == SA_SCHEDULE_TRIANGULAR && w.paired)
         sa_launch_peptide_pair(c->max_seq <= 52 ? 13 : 16, &P, grid, SA_LDS_FIXED_BYTES + SA_LDS_EMASK_BYTES, c->compute);
@@ -470,6 +478,7 @@ int sa_init(sa_ctx** out, const int32_t* S, int32_t gap, uint32_t max_seq_len, i
         h->gap = gap;
         h->max_len = max_seq_len;
         h->table_fits_i16 = table_fits_i16(h->S, gap);
+        h->table_fits_long = table_within(h->S, gap, 48);
         *out = h;
         return SA_OK;
     }
@@ -488,6 +497,7 @@ int sa_init(sa_ctx** out, const int32_t* S, int32_t gap, uint32_t max_seq_len, i
     c->gap = gap;
     c->max_len = max_seq_len;
     c->table_fits_i16 = table_fits_i16(c->S, gap);
+    c->table_fits_long = table_within(c->S, gap, 48);
     int rc = SA_OK;
     do {
         if ((e = hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking)) != hipSuccess) { rc = hip_code(e); break; }

@@ -1,0 +1,296 @@
+// sa_kernels_long_pair.hip -- TRIANGULAR, sequences longer than 64 residues, two first
+// sequences per wave in packed 16-bit cells (sa_pair_common.h).
+//
+// The sweep is the long-sequence kernel's (sa_kernels_long.hip): vertical strips of 64
+// columns, rows in blocks of four, the last column of a strip handed to the next strip
+// through a small global buffer.  D grows with the row index (up to length * max S'), far
+// beyond 16 bits, but inside one strip it cannot run away from the strip's left border:
+//   D[r][c] - D[r][c-1] <= max S'   and   D[r][c] - D[r-1][c] <= max S',   D monotone both ways,
+// so every lane keeps, per half, a base that follows its border column and the registers hold
+// D - base.  The recurrence only compares the three operands, so a common offset changes
+// neither the winner nor its tag; every 64 rows the base is moved up to the border value of
+// the row above and the difference is subtracted from the register row (64 subtractions per
+// 64 rows).  Between two moves a register holds at most (65 + 64) * max S' (border growth plus
+// growth along the strip): the host uses this kernel only for tables with 0 <= S' <= 48.
+// The border column travels between strips as absolute 32-bit values, one per half.
+#include "sa_pair_common.h"
+#include "sa_traceback.h"
+
+template <int WAVES_PER_SIMD>
+__global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_pair_kernel(const SaPepParams P) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    int32_t* const prof = reinterpret_cast<int32_t*>(smem);
+    uint8_t* const pseq = smem + SA_LDS_PROF_BYTES + 64;      // the two shared first sequences, lslot bytes each
+    const int lane = threadIdx.x;
+    const uint32_t rows_cap = P.lslot;
+    const uint32_t strips_cap = P.lslot >> 6;
+    const size_t half_dirs = (size_t)strips_cap * rows_cap * 256;              // dwords of direction rows per half
+    uint32_t* const dirs = P.spill + (size_t)blockIdx.x * 2 * half_dirs;
+    const size_t half_bcol = (size_t)2 * rows_cap * 64;                        // ints of border column per half
+    int32_t* const bcol = P.bcol + (size_t)blockIdx.x * 2 * half_bcol;
+    const int last_row = (int)rows_cap - 1;
+    // optional phase timers: 0 fetch, 2 operands, 3 fill, 4 traceback + record
+    const bool timed = P.phase_cycles != nullptr;
+    unsigned long long tph[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long tmark = timed ? __builtin_amdgcn_s_memtime() : 0;
+#define SA_PHASE(k) do { if (timed) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tph[k] += t_ - tmark; tmark = t_; } } while (0)
+
+    for (;;) {
+        uint32_t it = 0;
+        if (lane == 0) it = atomicAdd(P.counter, 1u);
+        it = __builtin_amdgcn_readfirstlane(it);
+        if (it >= P.nitems) break;
+        const SaItem item = P.items[it];
+        SA_PHASE(0);
+
+        const uint32_t p1 = item.p, p2 = item.reserved[0];
+        const bool has2 = p2 != SA_INVALID_FI;
+        const int lenp1 = P.len_fo[p1];
+        const int lenp2 = has2 ? (int)P.len_fo[p2] : 0;
+        __syncthreads();      // the previous item's walks are done with the copies
+        for (uint32_t o = lane * 16; o < P.lslot; o += 64 * 16) {
+            *reinterpret_cast<uint4*>(pseq + o) = *reinterpret_cast<const uint4*>(P.codes_fo + (size_t)p1 * P.lslot + o);
+            uint4 second = make_uint4(0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u);      // SA_PAD_CODE
+            if (has2) second = *reinterpret_cast<const uint4*>(P.codes_fo + (size_t)p2 * P.lslot + o);
+            *reinterpret_cast<uint4*>(pseq + P.lslot + o) = second;
+        }
+        __syncthreads();
+        const uint64_t n = P.nseq;
+        uint8_t* const out_row1 = P.out + ((uint64_t)p1 * (2 * n - p1 - 1) / 2 - P.out_base_pair) * P.stride;
+        uint8_t* const out_row2 = has2 ? P.out + ((uint64_t)p2 * (2 * n - p2 - 1) / 2 - P.out_base_pair) * P.stride : out_row1;
+        const int maxlenp = max(lenp1, lenp2);
+        const int nstrips = (maxlenp + 63) >> 6;
+        const int gend_last = ((maxlenp - 64 * (nstrips - 1)) + 3) >> 2;
+
+        for (uint32_t task = 0; task < item.count; task++) {
+            // ---------------------------------------------------------- operands
+            const uint32_t vbase = item.v0 + task * 64;
+            const uint32_t vl = vbase + lane;
+            const uint32_t nvalid = P.nseq - 1 - p1;
+            const bool active = vl < nvalid;
+            if (!__any(active)) continue;
+            uint32_t sidx = 0, cum = item.c0;
+            const uint32_t* cur_row = P.cursor + (size_t)p1 * P.nb;
+            for (uint32_t b = item.b0; b < P.nb; b++) {
+                const uint32_t first = P.bucket_base[b] + cur_row[b];
+                const uint32_t cnt = P.bucket_base[b + 1] - first;
+                if (vl >= cum && vl < cum + cnt) sidx = first + (vl - cum);
+                cum += cnt;
+                if (cum > vbase + 63) break;
+            }
+            const uint32_t fiq = P.fi_sorted[sidx];
+            const int lenq = active ? (int)P.len_sorted[sidx] : 0;
+            const bool active2 = active && has2 && fiq > p2;
+            const uint8_t* const bslot = P.codes_fo + (size_t)fiq * P.lslot;      // sequence 2 as one padded slot
+            const int maxlen = __builtin_amdgcn_readfirstlane(wave_max(lenq));
+            SA_PHASE(2);
+
+            // -------------------------------------------------------------- fill
+            int dfin1 = 0, dfin2 = 0;           // D at the last cell of each half, absolute
+            for (int s = 0; s < nstrips; s++) {
+                const int gend = (s == nstrips - 1) ? gend_last : SA_LP / 4;
+                {
+                    // packed query profile of columns 64s .. 64s+63 of the two first sequences
+                    const int a1 = pseq[64 * s + lane], a2 = pseq[P.lslot + 64 * s + lane];
+                    __syncthreads();
+#pragma unroll
+                    for (int b = 0; b < 20; b++)
+                        prof[b * SA_PROF_STRIDE + lane] = SA_PK_TABLE(P.sprime[a1 * SA_SPRIME_STRIDE + b]) |
+                                                          (SA_PK_TABLE(P.sprime[a2 * SA_SPRIME_STRIDE + b]) << 16);
+                    prof[20 * SA_PROF_STRIDE + lane] = SA_PK_TABLE(0) | (SA_PK_TABLE(0) << 16);
+                    __syncthreads();
+                }
+                uint32_t R[SA_LP], Q[SA_LP];
+#pragma unroll
+                for (int c = 0; c < SA_LP; c++) { R[c] = SA_PK_UP; Q[c] = SA_PK_UP; }     // border row, base 0
+                uint32_t e[8];
+#pragma unroll
+                for (int w = 0; w < 8; w++) e[w] = 0;
+                int base1 = 0, base2 = 0;
+                // border column: [half][strip parity][row / 4][lane][row % 4], absolute values
+                const int4* binA = reinterpret_cast<const int4*>(bcol + (size_t)(s & 1) * rows_cap * 64) + lane;
+                const int4* binB = reinterpret_cast<const int4*>(bcol + half_bcol + (size_t)(s & 1) * rows_cap * 64) + lane;
+                int4* boutA = reinterpret_cast<int4*>(bcol + (size_t)((s + 1) & 1) * rows_cap * 64) + lane;
+                int4* boutB = reinterpret_cast<int4*>(bcol + half_bcol + (size_t)((s + 1) & 1) * rows_cap * 64) + lane;
+                uint32_t* drowA = dirs + ((size_t)s * rows_cap * 64 + lane) * 4;
+                uint32_t* drowB = drowA + half_dirs;
+                const bool first_strip = s == 0, more_strips = s + 1 < nstrips;
+                const int half_word = (gend & 1) ? (gend - 1) >> 1 : -1;     // index of a half-full direction word, if any
+
+                auto residues4 = [&](int r) -> uint32_t {
+                    return *reinterpret_cast<const uint32_t*>(bslot + min(r, last_row - 3));
+                };
+                auto border4 = [&](const int4* bin, int r) -> int4 {
+                    return first_strip ? make_int4(0, 0, 0, 0) : bin[(size_t)(min(r, last_row - 3) >> 2) * 64];
+                };
+                // (a, b) relative to the bases, as a left operand: 4 * (D - base) in each half
+                auto rel = [&](int a, int b) -> uint32_t { return ((uint32_t)(a - base1) << 2) | ((uint32_t)(b - base2) << 18); };
+                // every lane stores its direction rows, also lanes whose sequence 2 has ended (never read):
+                // the stores of a block are then the same for every wave and the waits can be counted
+                auto store_dirs = [&](int r) {
+                    uint32_t lo[4], hi[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t w0 = e[2 * k] << ((half_word == 2 * k) ? 8 : 0);
+                        const uint32_t w1 = e[2 * k + 1] << ((half_word == 2 * k + 1) ? 8 : 0);
+                        lo[k] = __builtin_amdgcn_perm(w0, w1, 0x05040100u);     // low halves:  w0.lo : w1.lo
+                        hi[k] = __builtin_amdgcn_perm(w0, w1, 0x07060302u);     // high halves: w0.hi : w1.hi
+                    }
+                    *reinterpret_cast<uint4*>(drowA + (size_t)r * 256) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+                    *reinterpret_cast<uint4*>(drowB + (size_t)r * 256) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+                };
+
+                uint32_t bres = residues4(0);
+                int4 bordA = border4(binA, 0), bordB = border4(binB, 0);
+                int prevA = 0, prevB = 0;                        // border values of the row above the block
+                int4 sc0 = *reinterpret_cast<const int4*>(prof + (bres & 0xff) * SA_PROF_STRIDE), sc1 = sc0;
+#define SA_LP_ROW(IN, OUT, RR, DA, DB, LA, LB, B, BNEXT, SCI, SCO)                                                        \
+    if ((RR) < lenq)                                                                                                       \
+        fill_row_pair2(IN, OUT, gend, rel(DA, DB) | SA_PK_UP, rel(LA, LB), prof + (B) * SA_PROF_STRIDE,                    \
+                       prof + (BNEXT) * SA_PROF_STRIDE, SCI, SCO, e);                                                      \
+    store_dirs(RR);
+                for (int r = 0; r < maxlen; r += 4) {
+                    const uint32_t nres = residues4(r + 4);
+                    const int4 nbordA = border4(binA, r + 4), nbordB = border4(binB, r + 4);
+                    const uint32_t rb0 = bres & 0xff, rb1 = (bres >> 8) & 0xff, rb2 = (bres >> 16) & 0xff, rb3 = bres >> 24;
+                    if ((r & 63) == 0 && r > 0 && !first_strip) {
+                        // move the bases up to the border of the row above; the register row (R on a multiple of
+                        // four) follows.  Lanes whose sequence 2 has ended keep what they have.
+                        const int d1 = (r < lenq) ? prevA - base1 : 0, d2 = (r < lenq) ? prevB - base2 : 0;
+                        const uint32_t dd = ((uint32_t)d1 << 2) | ((uint32_t)d2 << 18);
+#pragma unroll
+                        for (int c = 0; c < SA_LP; c++) R[c] -= dd;
+                        base1 += d1; base2 += d2;
+                    }
+                    SA_LP_ROW(R, Q, r, prevA, prevB, bordA.x, bordB.x, rb0, rb1, sc0, sc1)
+                    const uint32_t y0 = Q[SA_LP - 1];
+                    SA_LP_ROW(Q, R, r + 1, bordA.x, bordB.x, bordA.y, bordB.y, rb1, rb2, sc1, sc0)
+                    const uint32_t y1 = R[SA_LP - 1];
+                    SA_LP_ROW(R, Q, r + 2, bordA.y, bordB.y, bordA.z, bordB.z, rb2, rb3, sc0, sc1)
+                    const uint32_t y2 = Q[SA_LP - 1];
+                    SA_LP_ROW(Q, R, r + 3, bordA.z, bordB.z, bordA.w, bordB.w, rb3, (nres & 0xff), sc1, sc0)
+                    const uint32_t y3 = R[SA_LP - 1];
+                    if (more_strips) {
+                        boutA[(size_t)(r >> 2) * 64] = make_int4((int)((y0 & 0xffffu) >> 2) + base1, (int)((y1 & 0xffffu) >> 2) + base1,
+                                                                 (int)((y2 & 0xffffu) >> 2) + base1, (int)((y3 & 0xffffu) >> 2) + base1);
+                        boutB[(size_t)(r >> 2) * 64] = make_int4((int)(y0 >> 18) + base2, (int)(y1 >> 18) + base2,
+                                                                 (int)(y2 >> 18) + base2, (int)(y3 >> 18) + base2);
+                    }
+                    prevA = bordA.w; prevB = bordB.w;
+                    bres = nres;
+                    bordA = nbordA; bordB = nbordB;
+                }
+#undef SA_LP_ROW
+                // the scores sit in the strips that hold each half's last column
+                if (((lenp1 - 1) >> 6) == s) {
+                    const uint32_t yq = pick_packed<SA_LP>(Q, (lenp1 - 1) & 63), yr = pick_packed<SA_LP>(R, (lenp1 - 1) & 63);
+                    dfin1 = (int)((((lenq & 1) ? yq : yr) & 0xffffu) >> 2) + base1;
+                }
+                if (has2 && ((lenp2 - 1) >> 6) == s) {
+                    const uint32_t yq = pick_packed<SA_LP>(Q, (lenp2 - 1) & 63), yr = pick_packed<SA_LP>(R, (lenp2 - 1) & 63);
+                    dfin2 = (int)(((lenq & 1) ? yq : yr) >> 18) + base2;
+                }
+                __syncthreads();   // border column and direction rows are complete before anyone reads them
+            }
+            SA_PHASE(3);
+
+            // --------------------------------------------------------- traceback, one half after the other
+            // One row per step, bottom row first, eight rows per 16-byte piece of the record.  The tags of a row
+            // are requested eight rows ahead for the strip the walk is in at that moment (a wrong guess is loaded
+            // again when it is used); the row residues come as two dwords a piece ahead; the first sequence is
+            // read from its LDS copy.  Tag layout: column c of a strip at bits 2(15 - c%16) of dword c/16.
+#pragma unroll 1
+            for (int half = 0; half < 2; half++) {
+                const bool act = half ? active2 : active;
+                if (!__any(act)) continue;
+                const int lenp = half ? lenp2 : lenp1;
+                const int lq = act ? lenq : 0;
+                const int mlen = __builtin_amdgcn_readfirstlane(wave_max(lq));
+                const uint32_t* hd = dirs + (half ? half_dirs : 0);
+                const uint8_t* ps = pseq + (half ? P.lslot : 0);
+                uint8_t* rec = (half ? out_row2 : out_row1) + (size_t)(fiq - (half ? p2 : p1) - 1) * P.stride;
+                int j = lenp, matches = 0, gaps = 0;
+                auto load_tags = [&](int sj, int r) -> uint4 {
+                    return *reinterpret_cast<const uint4*>(hd + (((size_t)sj * rows_cap + min(r, last_row)) * 64 + lane) * 4);
+                };
+                uint4 ring[8];
+                int ring_s[8];
+                const int ch0 = (mlen - 1) >> 3;
+                {
+                    const int s0 = (lenp - 1) >> 6;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) { ring[k] = load_tags(s0, 8 * ch0 + k); ring_s[k] = s0; }
+                }
+                uint2 resq = *reinterpret_cast<const uint2*>(bslot + min(8 * ch0, last_row - 7));
+                for (int ch = ch0; ch >= 0; --ch) {
+                    uint32_t w[4] = {0, 0, 0, 0};
+                    const uint2 res = resq;
+                    if (ch > 0) resq = *reinterpret_cast<const uint2*>(bslot + 8 * (ch - 1));
+#pragma unroll
+                    for (int k = 7; k >= 0; k--) {
+                        const int r = 8 * ch + k;
+                        if (r < lq) {
+                            int run_total = 0, t = 1;
+                            bool first = true;
+                            while (j > 0) {
+                                // L = trailing zeros from column j-1 down = 2 * (LEFT moves) + (1 if an UP ends the run)
+                                const int sj = (j - 1) >> 6, jl = ((j - 1) & 63) + 1;
+                                uint4 d;
+                                if (first && ring_s[k] == sj) d = ring[k];
+                                else d = load_tags(sj, r);
+                                first = false;
+                                const uint64_t v0 = ((uint64_t)d.x << 32) | d.y;
+                                const uint64_t v1 = ((uint64_t)d.z << 32) | d.w;
+                                const bool upper = jl > 32;
+                                const int jj = upper ? jl - 32 : jl;
+                                const uint64_t x = (upper ? v1 : v0) >> ((64 - 2 * jj) & 63);
+                                const int tz0 = v0 ? __builtin_ctzll(v0) : 64;
+                                const int L = x ? __builtin_ctzll(x) : (upper ? 2 * jj + tz0 : 64);
+                                const int run = min(L >> 1, jl);
+                                j -= run;
+                                run_total += run;
+                                if (run == jl && j > 0) continue;                     // the run goes on in the strip to the left
+                                if (run < jl) t = L & 1;
+                                break;
+                            }
+                            if (t == 0) {
+                                const uint32_t a = ps[j - 1];
+                                const uint32_t b = ((k < 4 ? res.x : res.y) >> (8 * (k & 3))) & 0xff;
+                                matches += (a == b) ? 1 : 0;
+                                j--;
+                            }
+                            gaps += t;
+                            w[k >> 1] |= (uint32_t)(run_total * 2 + t) << (16 * (k & 1));
+                        }
+                        if (ch > 0) {
+                            // the same row of the next piece, for the strip the walk is in now
+                            const int sn = (max(j, 1) - 1) >> 6;
+                            ring[k] = load_tags(sn, r - 8);
+                            ring_s[k] = sn;
+                        }
+                    }
+                    if (act)
+                        *reinterpret_cast<uint4*>(rec + SA_LONG_HEADER_BYTES + 16 * ch) = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+                if (act) {
+                    const int score = (half ? dfin2 : dfin1) + (lenp + lenq) * P.gap;
+                    *reinterpret_cast<uint4*>(rec) = make_uint4((uint32_t)score, (uint32_t)matches, (uint32_t)gaps, 0u);
+                    // rows past the last chunk are zero, so that equal inputs give equal records
+                    for (uint32_t o = SA_LONG_HEADER_BYTES + 16 * (((mlen - 1) >> 3) + 1); o < P.stride; o += 16)
+                        *reinterpret_cast<uint4*>(rec + o) = make_uint4(0, 0, 0, 0);
+                }
+            }
+            __syncthreads();
+            SA_PHASE(4);
+        }
+    }
+    if (timed && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) P.phase_cycles[(size_t)blockIdx.x * 8 + k] = tph[k];
+    }
+#undef SA_PHASE
+}
+
+extern "C" void sa_launch_long_pair(const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream) {
+    hipLaunchKernelGGL((sa_long_pair_kernel<2>), dim3(grid), dim3(64), lds_bytes, stream, *p);
+}

@@ -21,100 +21,8 @@
 // The lanes of a task are 64 consecutive entries of p1's valid list; the pair
 // (p2, q) exists only where q's file index is above p2 (all but the few sequences
 // between p1 and p2), elsewhere the high half is computed and dropped.
+#include "sa_pair_common.h"
 #include "sa_traceback.h"
-
-typedef short sa_i16x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(sa_i16x2, a), __builtin_bit_cast(sa_i16x2, b)));
-}
-
-#define SA_PK_TAGS 0x00030003u
-#define SA_PK_CLEAN 0xfffcfffcu
-#define SA_PK_UP 0x00020002u                         /* bank form of D = 0 in both halves */
-#define SA_PK_TABLE(sprime) (4 * (sprime) + 1)       /* table entry for a substitution score S' */
-
-// One packed cell.  The direction word of eight columns starts afresh at the first of
-// them (nothing is shifted across the 16-bit boundary: a word takes at most eight tags).
-// The tag and bank steps are written as instructions so that they stay where they are:
-// moved to the end of the row by the compiler they keep one more register per column
-// alive, and the row no longer fits the register file.
-#define SA_CELL_PK(IN, OUT, C, T, ACC)                                                   \
-    {                                                                                    \
-        const uint32_t diag_ = ((C) == 0) ? SA_PK_UP : IN[((C) == 0) ? 0 : (C) - 1];     \
-        const uint32_t m_ = diag_ + (uint32_t)(T);                                       \
-        const uint32_t h_ = pk_max(pk_max(m_, IN[C]), zl);                               \
-        if (((C) & 7) == 0) {                                                            \
-            asm volatile("v_and_b32 %0, 0x30003, %1" : "=v"(ACC) : "v"(h_));             \
-        } else {                                                                         \
-            uint32_t t_;                                                                 \
-            asm volatile("v_and_b32 %0, 0x30003, %1" : "=v"(t_) : "v"(h_));              \
-            asm volatile("v_lshl_or_b32 %0, %0, 2, %1" : "+v"(ACC) : "v"(t_));           \
-        }                                                                                \
-        zl = h_ & SA_PK_CLEAN;                                                           \
-        asm volatile("v_or_b32 %0, 0x20002, %1" : "=v"(OUT[C]) : "v"(zl));               \
-    }
-
-// Four columns.  Rows end early: gend = ceil(longer first sequence / 4).
-#define SA_GROUP_PK(G, CUR, NXT)                                                   \
-    NXT = *reinterpret_cast<const int4*>(row_base + 4 * ((G) + 1));                \
-    __builtin_amdgcn_sched_barrier(0);                                             \
-    SA_CELL_PK(IN, OUT, 4 * (G) + 0, CUR.x, e[(G) >> 1])                           \
-    SA_CELL_PK(IN, OUT, 4 * (G) + 1, CUR.y, e[(G) >> 1])                           \
-    SA_CELL_PK(IN, OUT, 4 * (G) + 2, CUR.z, e[(G) >> 1])                           \
-    SA_CELL_PK(IN, OUT, 4 * (G) + 3, CUR.w, e[(G) >> 1])                           \
-    if (NG == (G) + 1 || gend == (G) + 1) return;
-
-// One packed DP row: IN = previous row, OUT = this row, columns 0 .. 4*gend-1.
-// e[w] receives the tags of columns 8w .. 8w+7 of both pairs: column 8w+i at bits
-// 2(7-i) of each 16-bit half -- or, when the row ends after four columns of the word
-// (gend odd), column 8w+i at bits 2(3-i).
-template <int NG>
-__device__ __forceinline__ void fill_row_pair(const uint32_t (&IN)[4 * NG], uint32_t (&OUT)[4 * NG], const int gend,
-                                              const int32_t* __restrict__ row_base,
-                                              const int32_t* __restrict__ next_row_base, const int4& sc_in, int4& sc_out,
-                                              uint32_t (&e)[(NG + 1) / 2]) {
-    int4 scE = sc_in, scO;
-    uint32_t zl = 0;
-    sc_out = *reinterpret_cast<const int4*>(next_row_base);
-    SA_GROUP_PK(0, scE, scO)
-    SA_GROUP_PK(1, scO, scE)
-    SA_GROUP_PK(2, scE, scO)
-    SA_GROUP_PK(3, scO, scE)
-    SA_GROUP_PK(4, scE, scO)
-    SA_GROUP_PK(5, scO, scE)
-    SA_GROUP_PK(6, scE, scO)
-    SA_GROUP_PK(7, scO, scE)
-    SA_GROUP_PK(8, scE, scO)
-    SA_GROUP_PK(9, scO, scE)
-    SA_GROUP_PK(10, scE, scO)
-    SA_GROUP_PK(11, scO, scE)
-    SA_GROUP_PK(12, scE, scO)
-    if constexpr (NG > 13) {
-        SA_GROUP_PK(13, scO, scE)
-        SA_GROUP_PK(14, scE, scO)
-        SA_GROUP_PK(15, scO, scE)
-    }
-}
-
-// value of register column `col` (wave-uniform) of a packed row bank
-#define SA_PICK_PK(C) case C: v = BANK[(C) < NC ? (C) : 0]; break;
-template <int NC>
-__device__ __forceinline__ uint32_t pick_packed(const uint32_t (&BANK)[NC], const int col) {
-    uint32_t v = 0;
-    switch (col) {
-        SA_PICK_PK(0) SA_PICK_PK(1) SA_PICK_PK(2) SA_PICK_PK(3) SA_PICK_PK(4) SA_PICK_PK(5) SA_PICK_PK(6) SA_PICK_PK(7)
-        SA_PICK_PK(8) SA_PICK_PK(9) SA_PICK_PK(10) SA_PICK_PK(11) SA_PICK_PK(12) SA_PICK_PK(13) SA_PICK_PK(14) SA_PICK_PK(15)
-        SA_PICK_PK(16) SA_PICK_PK(17) SA_PICK_PK(18) SA_PICK_PK(19) SA_PICK_PK(20) SA_PICK_PK(21) SA_PICK_PK(22) SA_PICK_PK(23)
-        SA_PICK_PK(24) SA_PICK_PK(25) SA_PICK_PK(26) SA_PICK_PK(27) SA_PICK_PK(28) SA_PICK_PK(29) SA_PICK_PK(30) SA_PICK_PK(31)
-        SA_PICK_PK(32) SA_PICK_PK(33) SA_PICK_PK(34) SA_PICK_PK(35) SA_PICK_PK(36) SA_PICK_PK(37) SA_PICK_PK(38) SA_PICK_PK(39)
-        SA_PICK_PK(40) SA_PICK_PK(41) SA_PICK_PK(42) SA_PICK_PK(43) SA_PICK_PK(44) SA_PICK_PK(45) SA_PICK_PK(46) SA_PICK_PK(47)
-        SA_PICK_PK(48) SA_PICK_PK(49) SA_PICK_PK(50) SA_PICK_PK(51) SA_PICK_PK(52) SA_PICK_PK(53) SA_PICK_PK(54) SA_PICK_PK(55)
-        SA_PICK_PK(56) SA_PICK_PK(57) SA_PICK_PK(58) SA_PICK_PK(59) SA_PICK_PK(60) SA_PICK_PK(61) SA_PICK_PK(62) SA_PICK_PK(63)
-        default: break;
-    }
-    return v;
-}
 
 template <int NG, int WAVES_PER_SIMD>
 __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(const SaPepParams P) {
@@ -267,14 +175,14 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
                 asm volatile("" : "+s"(gr));
                 // every lane stores its direction row, also lanes whose sequence 2 has ended (those rows are never
                 // read): every wave then issues exactly four stores per iteration
-                if (r < lenq) fill_row_pair<NG>(R, Q, gr, prof + o0, prof + o1, sc0, sc0, e);
+                if (r < lenq) fill_row_pair<NG>(R, Q, gr, SA_PK_UP, 0u, prof + o0, prof + o1, sc0, sc0, e);
                 store_dirs(r, gr);
                 // Memory operations finish in the order they were issued: with at most the four direction stores
                 // of this iteration still in flight, the two residues requested before them have arrived.
                 uint32_t o2, o3;
                 asm volatile("s_waitcnt vmcnt(2)\n\tv_mul_u32_u24 %0, %2, %4\n\tv_mul_u32_u24 %1, %3, %4"
                              : "=&v"(o2), "=&v"(o3) : "v"(b2), "v"(b3), "s"(SA_PROF_STRIDE));
-                if (r + 1 < lenq) fill_row_pair<NG>(Q, R, gr, prof + o1, prof + o2, sc0, sc0, e);
+                if (r + 1 < lenq) fill_row_pair<NG>(Q, R, gr, SA_PK_UP, 0u, prof + o1, prof + o2, sc0, sc0, e);
                 store_dirs(r + 1, gr);
                 o0 = o2; o1 = o3;
             }

@@ -338,3 +338,42 @@ def test_negative_shifted_scores_take_the_unpaired_kernel():
     assert all(it[5] == 0xFFFFFFFF for it in al.work_items(sa.TRIANGULAR, 0, 199).tolist())
     rec = al.align(sa.TRIANGULAR, 0, 40)
     _check_pairs(al, rec, _tri_pairs(200, 0, 40), gap=3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,lo,hi,seed,alphabet", [(260, 65, 400, 41, ALPHABET), (150, 300, 1000, 42, ALPHABET),
+                                                   (120, 130, 330, 43, "AG"), (90, 700, 705, 44, ALPHABET)])
+def test_long_paired_and_unpaired_kernels_give_identical_records(n, lo, hi, seed, alphabet):
+    """Long sequences, two first sequences per wave with per-lane bases that move every 64 rows, against the
+    32-bit strip kernel (byte-identical records) and the checker (sampled rows).  The two-letter case makes
+    long runs of gaps and many ties."""
+    rng = random.Random(seed)
+    seqs = ["".join(rng.choice(alphabet) for _ in range(rng.randint(lo, hi))) for _ in range(n)]
+    al = sa.Aligner(max_seq_len=hi)
+    al.upload(seqs)
+    assert any(it[5] != 0xFFFFFFFF for it in al.work_items(sa.TRIANGULAR, 0, n - 1).tolist())
+    paired = al.align(sa.TRIANGULAR)
+    al.set_pairing(False)
+    assert all(it[5] == 0xFFFFFFFF for it in al.work_items(sa.TRIANGULAR, 0, n - 1).tolist())
+    unpaired = al.align(sa.TRIANGULAR)
+    assert np.array_equal(paired, unpaired)
+    for i in [0, n - 2] + [rng.randrange(n - 1) for _ in range(3)]:
+        first = al.pair_index(sa.TRIANGULAR, i)
+        pairs = [(i, j) for j in range(i + 1, n)][:40]
+        _check_pairs(al, paired[first : first + len(pairs)], pairs)
+
+
+@pytest.mark.gpu
+def test_long_paired_kernel_at_the_edge_of_its_range():
+    """S - 2*gap up to 48 is the most the long paired kernel takes (registers hold at most 4 * 129 * 48 + 3);
+    one more and the library must use 32-bit cells by itself.  Sequences of one letter reach the largest D."""
+    rng = random.Random(9)
+    seqs = ["".join(rng.choice("AAAR") for _ in range(rng.choice([400, 333, 256, 129]))) for _ in range(70)]
+    n = len(seqs)
+    for top, expect_pairs in ((40, True), (41, False)):
+        matrix = [top if a == b else top - rng.randint(0, 3) for a in range(20) for b in range(20)]
+        al = sa.Aligner(gap=-4, matrix=matrix, max_seq_len=400)
+        al.upload(seqs)
+        assert any(it[5] != 0xFFFFFFFF for it in al.work_items(sa.TRIANGULAR, 0, n - 1).tolist()) == expect_pairs
+        rec = al.align(sa.TRIANGULAR, 0, 6)
+        _check_pairs(al, rec, _tri_pairs(n, 0, 6), gap=-4, matrix=matrix)
