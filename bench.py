@@ -176,7 +176,7 @@ def main():
     if rank == 0:
         k_ms = sum(kernel_ms) / max(1, len(kernel_ms))
         if hi > 64:
-            kernel = "sa_long_kernel<0, 2>"
+            kernel = "sa_long_pair_kernel<2>"
         else:
             kernel = "sa_peptide_pair_kernel<13, 3>" if hi <= 52 else "sa_peptide_pair_kernel<16, 3>"
         achieved = my_cells * OPS_PER_CELL / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
@@ -192,7 +192,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "int32" if hi > 64 else "int16",
+            "dtype": "int16",
             "data": "synthetic",
             "config": {
                 "workload": desc,
@@ -214,7 +214,7 @@ def main():
                 "cells_per_launch": int(my_cells),
                 "ops_per_cell": OPS_PER_CELL,
                 "note": "INT32 VALU issue roofline (the path is not HBM- or MFMA-bound): algorithmic ops = 5 per DP cell "
-                        "(3 adds + 2 max of the reference recurrence); the peptide kernel packs two cells per lane "
+                        "(3 adds + 2 max of the reference recurrence); the kernels pack two cells per lane "
                         "(exact 16-bit arithmetic) and is still priced against the INT32 line; traffic = memory-side "
                         "bytes per launch from rocprofv3 PMC passes (profiles/), null when not measured",
             },

@@ -119,10 +119,10 @@ int sa_fetch_resident(sa_ctx* ctx, uint64_t first, uint64_t n, uint8_t* dst);
 /* tuning knobs of the peptide kernel: 64-pair tiles per work item, workgroups (waves)
  * per CU; 0 keeps the current value */
 int sa_set_tuning(sa_ctx* ctx, uint32_t tiles_per_item, uint32_t wg_per_cu);
-/* TRIANGULAR peptides (no sequence above 64) normally run on a kernel that handles two first
- * sequences per wave in packed 16-bit cells; it is used only when the substitution table allows
- * it (0 <= S - 2*gap <= 120 everywhere).  enable = 0 forces one first sequence per wave, 32-bit
- * cells (same results; for comparisons and tests).  Default: enabled. */
+/* TRIANGULAR work normally runs on kernels that handle two first sequences per wave in packed
+ * 16-bit cells; they are used only when the substitution table allows it (0 <= S - 2*gap <= 120
+ * everywhere when no sequence exceeds 64 residues, <= 48 otherwise).  enable = 0 forces one first
+ * sequence per wave, 32-bit cells (same results; for comparisons and tests).  Default: enabled. */
 int sa_set_pairing(sa_ctx* ctx, int enable);
 
 /* diagnostic: with enable != 0 the next launches accumulate shader cycles per kernel
