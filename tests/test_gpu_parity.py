@@ -377,3 +377,22 @@ def test_long_paired_kernel_at_the_edge_of_its_range():
         assert any(it[5] != 0xFFFFFFFF for it in al.work_items(sa.TRIANGULAR, 0, n - 1).tolist()) == expect_pairs
         rec = al.align(sa.TRIANGULAR, 0, 6)
         _check_pairs(al, rec, _tri_pairs(n, 0, 6), gap=-4, matrix=matrix)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("schedule", [sa.ADJACENT, sa.TRIANGULAR])
+def test_csv_driver_deals_chunks_to_several_contexts(tmp_path, schedule):
+    """The multi-GPU path of the CSV driver (chunk k -> context k % n, output in chunk order), rehearsed on
+    one card with three contexts on device 0: same bytes as the checker."""
+    seqs, labels = synth.generate(1500 if schedule == sa.TRIANGULAR else 40000, 3, 60, 91)
+    src = tmp_path / "in.csv"
+    synth.write_csv(str(src), seqs, labels)
+    want, got = tmp_path / "oracle.csv", tmp_path / "gpu.csv"
+    oracle_lib.run_file(str(src), str(want), schedule, threads=8)
+    st = sa.default_settings()
+    st.num_devices = 3
+    for k in range(3):
+        st.devices[k] = 0
+    rep = sa.run_csv(str(src), str(got), schedule, settings=st, pairs_per_submit=7000)
+    assert rep.chunks_done >= 6
+    assert got.read_bytes() == want.read_bytes()
