@@ -121,7 +121,10 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
             auto residue = [&](int r) -> uint32_t {
                 uint32_t v;
                 const int soff = min(r, SA_LP - 1) * (int)P.npad;
-                asm volatile("buffer_load_ubyte %0, %1, %2, %3 offen" : "=v"(v) : "v"(sidx), "s"(codes_t_words), "s"(soff) : "memory");
+                // s_nop 4: the scalar operands may have been written by a vector instruction just before (a restored
+                // register, v_readlane): a memory instruction needs five wait states after that, and the compiler
+                // does not insert them for instructions it cannot see into
+                asm volatile("s_nop 4\n\tbuffer_load_ubyte %0, %1, %2, %3 offen" : "=v"(v) : "v"(sidx), "s"(codes_t_words), "s"(soff) : "memory");
                 return v;
             };
             const int dir_lane = lane * wpr * 4;      // byte offset of this lane inside a direction row

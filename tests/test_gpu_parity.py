@@ -396,3 +396,17 @@ def test_csv_driver_deals_chunks_to_several_contexts(tmp_path, schedule):
     rep = sa.run_csv(str(src), str(got), schedule, settings=st, pairs_per_submit=7000)
     assert rep.chunks_done >= 6
     assert got.read_bytes() == want.read_bytes()
+
+
+@pytest.mark.gpu
+def test_few_sequences_in_one_bucket_pair_partners_of_any_length():
+    """200 sequences of 1..63 residues fall into a single length bucket: first sequences of very different
+    lengths share a wave of the paired kernel (64-column variant).  Every pair against the checker."""
+    seqs, _ = synth.generate(200, 1, 63, seed=3)
+    al = sa.Aligner()
+    al.upload(seqs)
+    n = len(seqs)
+    items = al.work_items(sa.TRIANGULAR, 0, n - 1).tolist()
+    assert any(it[5] != 0xFFFFFFFF for it in items)
+    rec = al.align(sa.TRIANGULAR)
+    _check_pairs(al, rec, _tri_pairs(n, 0, n - 1))
