@@ -29,24 +29,50 @@
 #ifndef GAP_PENALTY
 #define GAP_PENALTY -4
 #endif
+#ifndef READ_CSV_HEADER
 #define READ_CSV_HEADER "sequence,label\n"
+#endif
+#ifndef READ_CSV_SEQ_POS
 #define READ_CSV_SEQ_POS 0
+#endif
+#ifndef READ_CSV_COLS
 #define READ_CSV_COLS 2
+#endif
+#ifndef WRITE_CSV_HEADER
 #define WRITE_CSV_HEADER "sequence1,sequence2,label1,label2,score,alignment,matches,mismatches,gaps,similarity\n"
+#endif
+#ifndef WRITE_CSV_SEQ1_POS
 #define WRITE_CSV_SEQ1_POS 0
+#endif
+#ifndef WRITE_CSV_SCORE_POS
 #define WRITE_CSV_SCORE_POS 4
+#endif
+#ifndef WRITE_CSV_ALIGN_POS
 #define WRITE_CSV_ALIGN_POS 5
+#endif
+#ifndef WRITE_CSV_MATCHES_POS
 #define WRITE_CSV_MATCHES_POS 6
+#endif
+#ifndef WRITE_CSV_MISMATCHES_POS
 #define WRITE_CSV_MISMATCHES_POS 7
+#endif
+#ifndef WRITE_CSV_GAPS_POS
 #define WRITE_CSV_GAPS_POS 8
+#endif
+#ifndef WRITE_CSV_SIMILARITY_POS
 #define WRITE_CSV_SIMILARITY_POS 9
+#endif
+#ifndef WRITE_CSV_ALIGN_FMT
 #define WRITE_CSV_ALIGN_FMT "\"('%s', '%s')\""
+#endif
 #define INPUT_FILE getenv("SA_REF_INPUT")
 #define OUTPUT_FILE getenv("SA_REF_OUTPUT")
 #ifndef MODE_MULTITHREAD
 #define MODE_MULTITHREAD 0
 #endif
+#ifndef SIMILARITY_ANALYSIS
 #define SIMILARITY_ANALYSIS 1
+#endif
 #ifndef MODE_WRITE
 #define MODE_WRITE 1
 #endif

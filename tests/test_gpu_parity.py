@@ -410,3 +410,37 @@ def test_few_sequences_in_one_bucket_pair_partners_of_any_length():
     assert any(it[5] != 0xFFFFFFFF for it in items)
     rec = al.align(sa.TRIANGULAR)
     _check_pairs(al, rec, _tri_pairs(n, 0, n - 1))
+
+
+# ---- other input/output layouts, against what the reference itself writes (tests/golden/layout_*.csv,
+# produced by tests/golden/make_layout_fixtures.py from the reference compiled with those settings)
+
+def _layout_settings(name):
+    st = sa.default_settings()
+    st.read_csv_cols = 3
+    st.read_csv_seq_pos = 1
+    if name == "a":
+        st.write_csv_header = b"score,alignment,s1,s2,id1,id2,x1,x2,matches,gaps,similarity,mismatches\n"
+        st.write_csv_score_pos, st.write_csv_align_pos, st.write_csv_seq1_pos = 0, 1, 2
+        st.write_csv_matches_pos, st.write_csv_mismatches_pos = 8, 11
+        st.write_csv_gaps_pos, st.write_csv_similarity_pos = 9, 10
+    else:
+        st.similarity_analysis = 0
+        st.write_csv_header = b"id1,id2,x1,x2,s1,s2,score,alignment\n"
+        st.write_csv_seq1_pos, st.write_csv_score_pos, st.write_csv_align_pos = 4, 6, 7
+        st.write_csv_align_fmt = b"%s|%s"
+    return st
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["a", "b"])
+def test_other_csv_layouts_equal_the_reference_output(tmp_path, name):
+    golden = os.path.join(os.path.dirname(__file__), "golden")
+    out = tmp_path / "out.csv"
+    st = _layout_settings(name)
+    st.input_file = os.fsencode(os.path.join(golden, "layout_in.csv"))
+    st.output_file = os.fsencode(str(out))
+    rc, msg = sa.validate_settings(st)
+    assert rc == 0, msg
+    sa.run_csv(os.path.join(golden, "layout_in.csv"), str(out), sa.ADJACENT, settings=st)
+    assert out.read_bytes() == open(os.path.join(golden, f"layout_{name}_out.csv"), "rb").read()

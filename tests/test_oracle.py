@@ -123,3 +123,18 @@ def test_oracle_equals_compiled_reference_on_random_pairs():
         assert (o1, o2) == (a1.value, a2.value)
         assert (r.score, r.matches, r.mismatches, r.gaps) == (sc.value, m.value, mm.value, g.value)
         assert r.similarity_bp == int(sim.value * 10000)
+
+
+def test_layout_fixtures_agree_with_the_checker():
+    """The layout fixtures were written by the reference itself (tests/golden/make_layout_fixtures.py); the
+    checker must give the same score and aligned strings for every adjacent pair of their input."""
+    golden = os.path.join(os.path.dirname(__file__), "golden")
+    rows = [l.split(",") for l in open(os.path.join(golden, "layout_in.csv")).read().splitlines()[1:]]
+    out = open(os.path.join(golden, "layout_b_out.csv")).read().splitlines()[1:]
+    assert len(out) == len(rows) - 1
+    for k, line in enumerate(out):
+        id1, id2, x1, x2, s1, s2, score, alignment = line.split(",")
+        assert (id1, id2, x1, x2, s1, s2) == (rows[k][0], rows[k + 1][0], rows[k][0], rows[k + 1][0], rows[k][1], rows[k + 1][1])
+        a1, a2, r = oracle_lib.align(s1, s2)
+        assert int(score) == r.score
+        assert alignment == (a1 if isinstance(a1, str) else a1.decode()) + "|" + (a2 if isinstance(a2, str) else a2.decode())
