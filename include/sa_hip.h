@@ -108,6 +108,27 @@ int sa_submit(sa_ctx* ctx, int schedule, uint64_t row_begin, uint64_t row_end);
 int sa_next(sa_ctx* ctx, const uint8_t** records, uint64_t* first_pair, uint64_t* npairs);
 int sa_release(sa_ctx* ctx);
 
+/* ---- rows of CSV text written on the GPU.  Stands for the formatting the reference does on its main
+ * thread after a batch (buffer_output, include/csv.h:84-141; init_format, include/csv.h:38-82): a
+ * submission hands back the finished text of its pairs, in pair order, instead of records.
+ * sa_text_layout: what each output column shows (SA_TEXT_*; OTHER1/OTHER2 = the pass-through text of
+ * the pair's first / second input row) and the alignment format with its two "%s".
+ * sa_upload_passthrough: the pass-through text of every input row, row s at bytes[offs[s] .. offs[s+1]).
+ * sa_submit_text / sa_next_text mirror sa_submit / sa_next (same two slots, same sa_release); the text
+ * is copied to one of two pinned buffers of the context in turn and stays valid until the next-but-one
+ * sa_next_text on that context, also after sa_release. */
+enum { SA_TEXT_NONE = 0, SA_TEXT_SEQ1, SA_TEXT_SEQ2, SA_TEXT_SCORE, SA_TEXT_ALIGN, SA_TEXT_MATCHES, SA_TEXT_MISMATCHES,
+       SA_TEXT_GAPS, SA_TEXT_SIMILARITY, SA_TEXT_OTHER1, SA_TEXT_OTHER2 };
+typedef struct {
+    uint32_t ncols;
+    int8_t kind[32];
+    char align_fmt[128];
+} sa_text_layout;
+int sa_set_text_layout(sa_ctx* ctx, const sa_text_layout* layout);
+int sa_upload_passthrough(sa_ctx* ctx, const char* bytes, const uint64_t* offs, uint64_t nseq);
+int sa_submit_text(sa_ctx* ctx, int schedule, uint64_t row_begin, uint64_t row_end);
+int sa_next_text(sa_ctx* ctx, const char** text, uint64_t* nbytes, uint64_t* first_pair, uint64_t* npairs);
+
 /* ---- measurement: the same kernels with the records left in device memory.
  * sa_prepare_resident builds the work list and buffers for the row range once;
  * sa_run_resident launches the kernels over it (kernel_ms: HIP-event time on the

@@ -66,7 +66,7 @@ class Settings(C.Structure):
         ("format_threads", C.c_int32),
         ("pairs_per_submit", C.c_uint64),
         ("pairing", C.c_int32),
-        ("reserved", C.c_int32),
+        ("device_format", C.c_int32),
     ]
 
 
@@ -112,6 +112,10 @@ SIGNATURES = {
     "sa_fetch_resident": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, _u8p]),
     "sa_set_tuning": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     "sa_set_pairing": (C.c_int, [C.c_void_p, C.c_int]),
+    "sa_set_text_layout": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "sa_upload_passthrough": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.c_uint64]),
+    "sa_submit_text": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64]),
+    "sa_next_text": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "sa_expand_record": (
         C.c_int,
         [_u8p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_char_p, C.c_char_p,

@@ -21,6 +21,8 @@ extern "C" void sa_launch_peptide(int mode, int waves_per_simd, const SaPepParam
 extern "C" void sa_launch_pack_slots(const uint8_t* codes, const uint64_t* offs, const uint32_t* lens, uint64_t nseq,
                                      uint64_t nslots, uint32_t lslot, uint8_t* slots, uint16_t* len16, hipStream_t stream);
 extern "C" void sa_launch_peptide_pair(int ng, const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream);
+extern "C" size_t sa_format_scan_bytes(uint64_t n);
+extern "C" hipError_t sa_launch_format(const SaFormatParams* F, void* scan_tmp, size_t scan_bytes, hipStream_t stream);
 extern "C" void sa_launch_long_pair(const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream);
 extern "C" void sa_launch_long(int mode, const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream);
 
@@ -95,6 +97,10 @@ struct Work {                 // one submitted (or prepared) row range
     uint64_t first_pair = 0, npairs = 0;
     bool busy = false;
     bool paired = false;      // items were built for the paired kernel
+    // text submissions: row lengths, row offsets, text, total bytes, scan scratch; pinned total and text
+    DevBuf lens, offs, text, total, scan_tmp;
+    PinBuf host_total;
+    bool text_mode = false;
 };
 
 }  // namespace
@@ -132,6 +138,13 @@ struct sa_ctx {
     // device
     DevBuf d_codes, d_len, d_codes_t, d_fi_sorted, d_len_sorted, d_bucket_base, d_cursor, d_sprime, d_spill, d_phase, d_bcol, d_codes_s;
     bool phase_timers = false;
+    // device-side text
+    DevBuf d_other, d_other_off;
+    SaFormatParams fmt;
+    bool fmt_set = false, other_set = false;
+    uint32_t max_other = 0;
+    PinBuf text_ring[2];               // finished text goes to these in turn (valid until the next-but-one sa_next_text)
+    int text_ring_pos = 0;
     uint32_t spill_grid = 0;
     Work slots[2];
     int head = 0, tail = 0, inflight = 0;
@@ -415,6 +428,8 @@ int init_events(Work& w) {
 
 void free_work(Work& w) {
     w.items.release(); w.out.release(); w.counter.release(); w.host.release();
+    w.lens.release(); w.offs.release(); w.text.release(); w.total.release(); w.scan_tmp.release();
+    w.host_total.release();
     if (w.kernel_done) (void)hipEventDestroy(w.kernel_done);
     if (w.copied) (void)hipEventDestroy(w.copied);
     if (w.t0) (void)hipEventDestroy(w.t0);
@@ -527,6 +542,8 @@ void sa_destroy(sa_ctx* c) {
     c->d_codes.release(); c->d_len.release(); c->d_codes_t.release(); c->d_fi_sorted.release();
     c->d_len_sorted.release(); c->d_bucket_base.release(); c->d_cursor.release(); c->d_sprime.release();
     c->d_spill.release(); c->d_bcol.release(); c->d_codes_s.release();
+    c->d_other.release(); c->d_other_off.release();
+    c->text_ring[0].release(); c->text_ring[1].release();
     c->d_phase.release();
     if (c->compute) (void)hipStreamDestroy(c->compute);
     if (c->copy) (void)hipStreamDestroy(c->copy);
@@ -685,6 +702,7 @@ int sa_submit(sa_ctx* c, int schedule, uint64_t r0, uint64_t r1) {
         SA_HIP_TRY(hipMemcpyAsync(w.host.p, w.out.p, w.npairs * (size_t)c->stride, hipMemcpyDeviceToHost, c->copy));
     SA_HIP_TRY(hipEventRecord(w.copied, c->copy));
     w.busy = true;
+    w.text_mode = false;
     c->head ^= 1;
     c->inflight++;
     return SA_OK;
@@ -694,6 +712,7 @@ int sa_next(sa_ctx* c, const uint8_t** records, uint64_t* first_pair, uint64_t* 
     if (!c || !records || !first_pair || !npairs) return SA_ERR_ARG;
     if (c->inflight == 0) return SA_ERR_STATE;
     Work& w = c->slots[c->tail];
+    if (w.text_mode) return SA_ERR_STATE;
     SA_HIP_TRY(hipEventSynchronize(w.copied));
     *records = (const uint8_t*)w.host.p;
     *first_pair = w.first_pair;
@@ -707,6 +726,131 @@ int sa_release(sa_ctx* c) {
     c->slots[c->tail].busy = false;
     c->tail ^= 1;
     c->inflight--;
+    return SA_OK;
+}
+
+int sa_set_text_layout(sa_ctx* c, const sa_text_layout* L) {
+    if (!c || !L || L->ncols == 0 || L->ncols > SA_FMT_MAX_COLS) return SA_ERR_ARG;
+    memset(&c->fmt, 0, sizeof(c->fmt));
+    c->fmt.ncols = L->ncols;
+    for (uint32_t k = 0; k < L->ncols; k++) {
+        if (L->kind[k] < SA_TEXT_NONE || L->kind[k] > SA_TEXT_OTHER2) return SA_ERR_ARG;
+        c->fmt.kind[k] = L->kind[k];
+    }
+    // the format is split at its two "%s" (include/csv.h:40-54)
+    const char* f = L->align_fmt;
+    const char* end = f + strnlen(L->align_fmt, sizeof(L->align_fmt));
+    uint32_t part = 0;
+    const char* from = f;
+    while (f < end) {
+        if (f[0] == '%' && f + 1 < end && f[1] == 's' && part < 2) {
+            c->fmt.part_len[part] = (uint32_t)(f - from);
+            memcpy(c->fmt.part[part], from, c->fmt.part_len[part]);
+            f += 2; from = f; part++;
+        } else f++;
+    }
+    if (part != 2) return SA_ERR_ARG;
+    c->fmt.part_len[2] = (uint32_t)(end - from);
+    memcpy(c->fmt.part[2], from, c->fmt.part_len[2]);
+    memcpy(c->fmt.alphabet, SA_ALPHABET "-", 21);
+    c->fmt_set = true;
+    return SA_OK;
+}
+
+int sa_upload_passthrough(sa_ctx* c, const char* bytes, const uint64_t* offs, uint64_t nseq) {
+    if (!c || !offs || (!bytes && offs[nseq] != 0)) return SA_ERR_ARG;
+    if (c->device == SA_DEVICE_NONE || nseq != c->nseq) return SA_ERR_STATE;
+    if (offs[nseq] >= 0xFFFFFFF0ull) return SA_ERR_NOMEM;
+    SA_HIP_TRY(hipSetDevice(c->device));
+    std::vector<uint32_t> o32(nseq + 1);
+    uint32_t longest = 0;
+    for (uint64_t s = 0; s <= nseq; s++) {
+        o32[s] = (uint32_t)offs[s];
+        if (s && offs[s] < offs[s - 1]) return SA_ERR_ARG;
+        if (s) longest = std::max(longest, (uint32_t)(offs[s] - offs[s - 1]));
+    }
+    int rc;
+    if ((rc = c->d_other.reserve(std::max<size_t>(16, offs[nseq])))) return rc;
+    if ((rc = c->d_other_off.reserve(o32.size() * 4))) return rc;
+    if (offs[nseq]) SA_HIP_TRY(hipMemcpy(c->d_other.p, bytes, offs[nseq], hipMemcpyHostToDevice));
+    SA_HIP_TRY(hipMemcpy(c->d_other_off.p, o32.data(), o32.size() * 4, hipMemcpyHostToDevice));
+    c->max_other = longest;
+    c->other_set = true;
+    return SA_OK;
+}
+
+int sa_submit_text(sa_ctx* c, int schedule, uint64_t r0, uint64_t r1) {
+    if (!c || (schedule != SA_SCHEDULE_ADJACENT && schedule != SA_SCHEDULE_TRIANGULAR)) return SA_ERR_ARG;
+    if (c->nseq < 2 || c->device == SA_DEVICE_NONE || !c->fmt_set || !c->other_set) return SA_ERR_STATE;
+    if (r1 < r0 || r1 > sa_schedule_rows(c, schedule)) return SA_ERR_ARG;
+    if (c->inflight == 2) return SA_ERR_BUSY;
+    SA_HIP_TRY(hipSetDevice(c->device));
+    Work& w = c->slots[c->head];
+    int rc = prepare_work(c, w, schedule, r0, r1, false);
+    if (rc) return rc;
+    if ((rc = launch_work(c, w, false))) return rc;
+    if (w.npairs) {
+        // longest possible row: both sequences, both aligned strings (at most len1 + len2 columns each),
+        // the pass-through columns, the format parts, five numbers, separators
+        const size_t lmax = c->max_seq;
+        const size_t bound = 6 * lmax + (size_t)c->fmt.ncols * (c->max_other + 1) + c->fmt.part_len[0] + c->fmt.part_len[1] +
+                             c->fmt.part_len[2] + 5 * 12 + 8;
+        const size_t scan_bytes = sa_format_scan_bytes(w.npairs);
+        if ((rc = w.lens.reserve(w.npairs * 4)) || (rc = w.offs.reserve(w.npairs * 8)) || (rc = w.total.reserve(8)) ||
+            (rc = w.scan_tmp.reserve(std::max<size_t>(16, scan_bytes))) || (rc = w.text.reserve(w.npairs * bound)) ||
+            (rc = w.host_total.reserve(8)))
+            return rc;
+        SaFormatParams F = c->fmt;
+        F.codes_fo = (const uint8_t*)c->d_codes.p;
+        F.len_fo = (const uint16_t*)c->d_len.p;
+        F.lslot = c->lslot;
+        F.rec = (const uint8_t*)w.out.p;
+        F.stride = c->stride;
+        F.row_bytes = c->row_bytes;
+        F.first_pair = w.first_pair;
+        F.npairs = w.npairs;
+        F.nseq = c->nseq;
+        F.schedule = schedule;
+        F.other = (const char*)c->d_other.p;
+        F.other_off = (const uint32_t*)c->d_other_off.p;
+        F.lens = (uint32_t*)w.lens.p;
+        F.offs = (uint64_t*)w.offs.p;
+        F.text = (char*)w.text.p;
+        F.total = (uint64_t*)w.total.p;
+        SA_HIP_TRY(sa_launch_format(&F, w.scan_tmp.p, scan_bytes, c->compute));
+        SA_HIP_TRY(hipMemcpyAsync(w.host_total.p, w.total.p, 8, hipMemcpyDeviceToHost, c->compute));
+    }
+    SA_HIP_TRY(hipEventRecord(w.kernel_done, c->compute));
+    w.busy = true;
+    w.text_mode = true;
+    c->head ^= 1;
+    c->inflight++;
+    return SA_OK;
+}
+
+int sa_next_text(sa_ctx* c, const char** text, uint64_t* nbytes, uint64_t* first_pair, uint64_t* npairs) {
+    if (!c || !text || !nbytes || !first_pair || !npairs) return SA_ERR_ARG;
+    if (c->inflight == 0) return SA_ERR_STATE;
+    Work& w = c->slots[c->tail];
+    if (!w.text_mode) return SA_ERR_STATE;
+    SA_HIP_TRY(hipSetDevice(c->device));
+    SA_HIP_TRY(hipEventSynchronize(w.kernel_done));
+    uint64_t total = 0;
+    if (w.npairs) {
+        total = *(const uint64_t*)w.host_total.p;
+    }
+    PinBuf& dst = c->text_ring[c->text_ring_pos];
+    c->text_ring_pos ^= 1;
+    int rc = dst.reserve(std::max<size_t>(16, total));
+    if (rc) return rc;
+    if (total) {
+        SA_HIP_TRY(hipMemcpyAsync(dst.p, w.text.p, total, hipMemcpyDeviceToHost, c->copy));
+        SA_HIP_TRY(hipStreamSynchronize(c->copy));
+    }
+    *text = (const char*)dst.p;
+    *nbytes = total;
+    *first_pair = w.first_pair;
+    *npairs = w.npairs;
     return SA_OK;
 }
 

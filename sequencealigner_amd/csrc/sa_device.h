@@ -96,4 +96,32 @@ typedef struct {
     int32_t* bcol;               /* per workgroup 2 x lslot x 64: last DP column of a strip, for the next strip */
 } SaPepParams;
 
+
+/* ---- rows of CSV text written on the device (sa_format.hip) */
+enum { SA_COL_NONE = 0, SA_COL_SEQ1, SA_COL_SEQ2, SA_COL_SCORE, SA_COL_ALIGN, SA_COL_MATCHES, SA_COL_MISMATCHES,
+       SA_COL_GAPS, SA_COL_SIMILARITY, SA_COL_OTHER1, SA_COL_OTHER2 };
+#define SA_FMT_MAX_COLS 32
+#define SA_FMT_PART_BYTES 128
+
+typedef struct {
+    const uint8_t* codes_fo;      /* file-order slots of residue codes */
+    const uint16_t* len_fo;
+    uint32_t lslot;
+    const uint8_t* rec;           /* records of the submission, device memory */
+    uint32_t stride, row_bytes;
+    uint64_t first_pair, npairs, nseq;
+    int32_t schedule;
+    const char* other;            /* pass-through text of every input row: other[other_off[s] .. other_off[s+1]) */
+    const uint32_t* other_off;
+    uint32_t ncols;
+    int8_t kind[SA_FMT_MAX_COLS]; /* SA_COL_* per output column */
+    char part[3][SA_FMT_PART_BYTES];   /* the alignment format split at its two "%s" */
+    uint32_t part_len[3];
+    char alphabet[24];
+    uint32_t* lens;               /* [npairs] row lengths */
+    uint64_t* offs;               /* [npairs] row offsets in text */
+    char* text;
+    uint64_t* total;              /* bytes of text of the submission */
+} SaFormatParams;
+
 #endif

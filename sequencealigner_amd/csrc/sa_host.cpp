@@ -262,7 +262,7 @@ void sa_settings_default(sa_settings* st) {
     st->format_threads = 0;
     st->pairs_per_submit = 0;
     st->pairing = 1;
-    st->reserved = 0;
+    st->device_format = 1;
 }
 
 static bool parse_c_string(const char* p, char* out, size_t cap) {
@@ -424,6 +424,26 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
             rc = sa_upload(ctx[(size_t)d], codes.data(), offs.data(), lens.data(), n);
             if (rc) { cleanup(); if (out_fd >= 0) close(out_fd); return fail(rc); }
         }
+        const bool text_mode = st->mode_write && st->device_format;
+        if (text_mode) {
+            // the rows are written on the GPU: it needs the layout and the pass-through text of every input row
+            sa_text_layout tl;
+            memset(&tl, 0, sizeof(tl));
+            tl.ncols = L.ncols;
+            for (uint32_t k = 0; k < L.ncols && k < 32; k++) tl.kind[k] = (int8_t)L.kind[k];
+            snprintf(tl.align_fmt, sizeof(tl.align_fmt), "%s", st->write_csv_align_fmt);
+            std::vector<uint64_t> ooff(n + 1, 0);
+            for (uint64_t s = 0; s < n; s++) ooff[s + 1] = ooff[s] + tab.rows[s].other_len;
+            std::vector<char> obytes(ooff[n] + 1);
+            sa_parallel_for(n, 1 << 16, [&](uint64_t lo, uint64_t hi, unsigned) {
+                for (uint64_t s = lo; s < hi; s++) memcpy(obytes.data() + ooff[s], tab.rows[s].other, tab.rows[s].other_len);
+            });
+            for (int d = 0; d < ndev && rc == SA_OK; d++) {
+                rc = L.ncols <= 32 ? sa_set_text_layout(ctx[(size_t)d], &tl) : SA_ERR_ARG;
+                if (rc == SA_OK) rc = sa_upload_passthrough(ctx[(size_t)d], obytes.data(), ooff.data(), n);
+            }
+            if (rc) { cleanup(); if (out_fd >= 0) close(out_fd); return fail(rc); }
+        }
         rep->seconds_upload = now_s() - tu0;
         const int schedule = st->schedule;
         const uint64_t rows = sa_schedule_rows(ctx[0], schedule);
@@ -434,6 +454,8 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
 
         // chunks of whole schedule rows; chunk k goes to device k % ndev, results are consumed in chunk order
         uint64_t cap = st->pairs_per_submit ? st->pairs_per_submit : (uint64_t)st->batch_size * 4;   // 262144 at the default BATCH_SIZE: the best of the tuner's sweep with writing on
+        // text submissions keep a worst-case text buffer per pair on the device: at most about 1 GiB per submission
+        if (text_mode) cap = std::min<uint64_t>(cap, std::max<uint64_t>(1024, (1ull << 30) / (6ull * st->max_seq_len + 600)));
         if (cap < 1) cap = 1;
         std::vector<Chunk> chunks;
         for (uint64_t r0 = 0; r0 < rows;) {
@@ -452,6 +474,7 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
         std::atomic<uint64_t> written(0);
         uint64_t file_off = strlen(st->write_csv_header);       // where the next chunk's text starts in the file
         int cur_set = 0;
+        std::thread text_writer;          // text submissions: the writer of the previous chunk
         const size_t row_bound = 4 * (size_t)st->max_seq_len + 2 * 256 + L.part[0].size() + L.part[1].size() + L.part[2].size() + 64;
 
         size_t next_submit = 0;
@@ -459,7 +482,8 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
             // keep up to two chunks in flight per device, in chunk order
             while (next_submit < chunks.size() && next_submit < rep->chunks_done + 2 * (size_t)ndev) {
                 sa_ctx* c = ctx[next_submit % (size_t)ndev];
-                int r = sa_submit(c, schedule, chunks[next_submit].r0, chunks[next_submit].r1);
+                int r = text_mode ? sa_submit_text(c, schedule, chunks[next_submit].r0, chunks[next_submit].r1)
+                                  : sa_submit(c, schedule, chunks[next_submit].r0, chunks[next_submit].r1);
                 if (r == SA_ERR_BUSY) break;
                 if (r) return r;
                 next_submit++;
@@ -472,6 +496,29 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
             const uint8_t* recs = nullptr;
             uint64_t first = 0, np = 0;
             const double tw0 = now_s();
+            if (text_mode) {
+                const char* text = nullptr;
+                uint64_t nbytes = 0;
+                if ((rc = sa_next_text(c, &text, &nbytes, &first, &np))) break;
+                t_wait += now_s() - tw0;
+                // Finished rows: the slot is free again at once (the text sits in a buffer of the context that
+                // stays valid over the next call); a writer thread (with helpers) puts the slices of the text at
+                // their place in the file while the next submission is awaited.
+                if ((rc = sa_release(c))) break;
+                const double tw1 = now_s();
+                if (text_writer.joinable()) text_writer.join();
+                t_write += now_s() - tw1;
+                const uint64_t at = file_off;
+                file_off += nbytes;
+                text_writer = std::thread([text, nbytes, at, out_fd, &write_failed, &written]() {
+                    sa_parallel_for(nbytes, 1 << 22, [&](uint64_t lo, uint64_t hi, unsigned) {
+                        if (!pwrite_all(out_fd, text + lo, hi - lo, at + lo)) write_failed.store(true);
+                    });
+                    written.fetch_add(nbytes);
+                });
+                rep->chunks_done++;
+                continue;
+            }
             if ((rc = sa_next(c, &recs, &first, &np))) break;
             t_wait += now_s() - tw0;
             if (st->mode_write && np) {
@@ -541,6 +588,7 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
             rep->chunks_done++;
         }
         const double tj2 = now_s();
+        if (text_writer.joinable()) text_writer.join();
         for (auto& w : writer) if (w.joinable()) w.join();
         t_write += now_s() - tj2;
         rep->bytes_written += written.load();

@@ -13,7 +13,7 @@ static void usage(const char* argv0) {
     fprintf(stderr,
             "usage: %s [--config user.h] [--input in.csv] [--output out.csv]\n"
             "          [--schedule adjacent|triangular] [--gap N] [--max-seq-len N]\n"
-            "          [--devices N] [--threads N] [--pairs-per-submit N] [--no-write] [--no-pairing]\n",
+            "          [--devices N] [--threads N] [--pairs-per-submit N] [--no-write] [--no-pairing] [--host-format]\n",
             argv0);
 }
 
@@ -41,6 +41,7 @@ int main(int argc, char** argv) {
         else if (!strcmp(a, "--pairs-per-submit")) st.pairs_per_submit = strtoull(need(a), nullptr, 10);
         else if (!strcmp(a, "--no-write")) st.mode_write = 0;
         else if (!strcmp(a, "--no-pairing")) st.pairing = 0;
+        else if (!strcmp(a, "--host-format")) st.device_format = 0;
         else { usage(argv[0]); return 2; }
     }
     char msg[256];

@@ -444,3 +444,24 @@ def test_other_csv_layouts_equal_the_reference_output(tmp_path, name):
     assert rc == 0, msg
     sa.run_csv(os.path.join(golden, "layout_in.csv"), str(out), sa.ADJACENT, settings=st)
     assert out.read_bytes() == open(os.path.join(golden, f"layout_{name}_out.csv"), "rb").read()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["a", "b"])
+def test_host_formatting_path_equals_the_reference_output(tmp_path, name):
+    """device_format = 0: records come back and host threads format them (the default writes the rows on the GPU)."""
+    golden = os.path.join(os.path.dirname(__file__), "golden")
+    out = tmp_path / "out.csv"
+    st = _layout_settings(name)
+    st.device_format = 0
+    sa.run_csv(os.path.join(golden, "layout_in.csv"), str(out), sa.ADJACENT, settings=st)
+    assert out.read_bytes() == open(os.path.join(golden, f"layout_{name}_out.csv"), "rb").read()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("schedule,key", [(sa.ADJACENT, "avpdb_adjacent_out"), (sa.TRIANGULAR, "avpdb_triangular_out")])
+def test_host_formatting_path_on_the_reference_data_set(tmp_path, schedule, key):
+    from conftest import HASHES
+    out = tmp_path / "out.csv"
+    sa.run_csv(os.path.join(os.path.dirname(__file__), "golden", "avpdb.csv"), str(out), schedule, device_format=0)
+    assert sha256_file(str(out)) == HASHES[key]
