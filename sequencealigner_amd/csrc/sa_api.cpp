@@ -11,6 +11,7 @@
 #include <cstring>
 #include <new>
 #include <vector>
+#include <time.h>
 
 #include "../../include/sa_hip.h"
 #include "sa_device.h"
@@ -122,9 +123,8 @@ struct sa_ctx {
     // sequences (host mirror)
     uint64_t nseq = 0;
     std::vector<uint16_t> len;         // file order
-    std::vector<uint64_t> len_suffix;  // len_suffix[i] = sum of len[i..]
-    std::vector<uint8_t> codes_host;   // concatenated residue codes, file order
-    std::vector<uint64_t> offs_host;
+    std::vector<uint64_t> len_suffix;  // len_suffix[i] = sum of len[i..]; built on first TRIANGULAR use
+    std::vector<uint8_t> slots_host;   // file-order slots: host-only contexts, or read back from the device for the bucket order
     uint32_t min_seq = 0, max_seq = 0; // shortest / longest uploaded sequence
     uint32_t stride = 80;
     uint32_t lslot = SA_LP;            // bytes per file-order slot; > 64 selects the long-sequence kernel
@@ -170,9 +170,22 @@ bool table_within(const int32_t* S, int32_t gap, int64_t top) {
 bool table_fits_i16(const int32_t* S, int32_t gap) { return table_within(S, gap, 120); }
 
 // Bucket order of the sequences and the cursor table (see sa_device.h); TRIANGULAR only.
+void ensure_suffix(sa_ctx* c) {
+    if (c->len_suffix.size() == c->nseq + 1) return;
+    c->len_suffix.assign(c->nseq + 1, 0);
+    for (uint64_t s = c->nseq; s-- > 0;) c->len_suffix[s] = c->len_suffix[s + 1] + c->len[s];
+}
+
 int ensure_triangular(sa_ctx* c) {
     if (c->tri_ready) return SA_OK;
     const uint64_t n = c->nseq;
+    ensure_suffix(c);
+    if (c->slots_host.empty()) {
+        // the residue codes live on the device only (the upload keeps no second host copy: the 4 M-row
+        // ADJACENT run never needs one); the bucket order is built from the slots read back
+        c->slots_host.resize((size_t)(n + 2) * c->lslot);
+        SA_HIP_TRY(hipMemcpy(c->slots_host.data(), c->d_codes.p, c->slots_host.size(), hipMemcpyDeviceToHost));
+    }
     // length buckets: exact lengths when every length has plenty of sequences, wider otherwise
     const uint32_t range = c->max_seq - c->min_seq + 1;
     uint32_t width = (uint32_t)((256ull * range + n - 1) / n);
@@ -203,7 +216,7 @@ int ensure_triangular(sa_ctx* c) {
         const uint32_t slot = fill[b]++;
         c->fi_sorted[slot] = (uint32_t)s;
         len_sorted[slot] = c->len[s];
-        const uint8_t* src = c->codes_host.data() + c->offs_host[s];
+        const uint8_t* src = c->slots_host.data() + (size_t)s * c->lslot;
         for (uint32_t i = 0; i < c->len[s]; i++) codes_t[(size_t)i * c->npad + slot] = src[i];
         if (!lng) memcpy(&codes_s[(size_t)slot * SA_LP], src, c->len[s]);
         running[b]++;
@@ -601,15 +614,17 @@ int sa_upload(sa_ctx* c, const uint8_t* codes, const uint64_t* offs, const uint3
 
     // host mirrors: lengths, suffix sums of the lengths, the caller's arrays
     c->len.resize(nseq);
-    c->offs_host.resize(nseq);
-    c->codes_host.resize(total);
     sa_parallel_for(nseq, 1 << 16, [&](uint64_t lo, uint64_t hi, unsigned) {
-        for (uint64_t s = lo; s < hi; s++) { c->len[s] = (uint16_t)lens[s]; c->offs_host[s] = offs[s]; }
+        for (uint64_t s = lo; s < hi; s++) c->len[s] = (uint16_t)lens[s];
     });
-    sa_parallel_for(total, 1 << 22, [&](uint64_t lo, uint64_t hi, unsigned) { memcpy(c->codes_host.data() + lo, codes + lo, hi - lo); });
-    c->len_suffix.resize(nseq + 1);
-    c->len_suffix[nseq] = 0;
-    for (uint64_t s = nseq; s-- > 0;) c->len_suffix[s] = c->len_suffix[s + 1] + c->len[s];
+    c->len_suffix.clear();
+    if (c->device == SA_DEVICE_NONE) {
+        // no device to read the slots back from: a host-only context keeps them itself
+        c->slots_host.assign((size_t)(nseq + 2) * lslot, SA_PAD_CODE);
+        for (uint64_t s = 0; s < nseq; s++) memcpy(&c->slots_host[(size_t)s * lslot], codes + offs[s], lens[s]);
+    } else {
+        c->slots_host.clear();
+    }
     if (c->device == SA_DEVICE_NONE) return SA_OK;
 
     // device: the compact arrays go up as they are; a kernel spreads them into the file-order
@@ -656,6 +671,7 @@ uint64_t sa_pair_count(const sa_ctx* c, int schedule, uint64_t r0, uint64_t r1) 
 
 uint64_t sa_cell_count(const sa_ctx* c, int schedule, uint64_t r0, uint64_t r1) {
     if (!c || r1 <= r0) return 0;
+    if (schedule != SA_SCHEDULE_ADJACENT) ensure_suffix(const_cast<sa_ctx*>(c));     // a cache, built once
     uint64_t cells = 0;
     for (uint64_t i = r0; i < r1; i++) {
         if (schedule == SA_SCHEDULE_ADJACENT) cells += (uint64_t)c->len[i] * c->len[i + 1];

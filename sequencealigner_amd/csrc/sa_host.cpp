@@ -15,6 +15,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -42,8 +44,15 @@ struct Table {
     char* data = nullptr;
     size_t size = 0;
     int fd = -1;
-    std::vector<Row> rows;
+    Row* rows_data = nullptr;     // rows in file order (filled by several threads, never value-initialised)
+    size_t nrows = 0;
+    struct RowView {
+        const Row* p; size_t n;
+        size_t size() const { return n; }
+        const Row& operator[](size_t k) const { return p[k]; }
+    } rows{nullptr, 0};
     ~Table() {
+        free(rows_data);
         if (data && data != MAP_FAILED) munmap(data, size);
         if (fd >= 0) close(fd);
     }
@@ -71,8 +80,9 @@ int load_table(const sa_settings* st, Table& t, std::string& err) {
     const char* stop = (const char*)memchr(body, 0, (size_t)(end - body));
     if (!stop) stop = end;
     const uint32_t seq_pos = st->read_csv_seq_pos;
-    auto parse = [seq_pos](const char* p, const char* lim, std::vector<Row>& rows) {
-        rows.reserve((size_t)(lim - p) / 24 + 16);
+    // rows == nullptr: count only
+    auto parse = [seq_pos](const char* p, const char* lim, Row* rows) -> size_t {
+        size_t count = 0;
         while (p < lim) {
             while (p < lim && (*p == ' ' || *p == '\r' || *p == '\n')) p++;
             if (p >= lim) break;
@@ -87,29 +97,36 @@ int load_table(const sa_settings* st, Table& t, std::string& err) {
                 if (p < lim && *p == ',') { p++; col++; }
             }
             if (!r.seq) { r.seq = p; r.len = 0; }
-            rows.push_back(r);
+            if (rows) rows[count] = r;
+            count++;
             while (p < lim && (*p == '\n' || *p == '\r')) p++;
         }
+        return count;
     };
+    // a slice owns the lines that begin in it: both ends move forward to the next line start.  Two passes
+    // over the slices: count the rows, then write them to their place in one array.
     const uint64_t bytes = (uint64_t)(stop - body);
-    std::vector<std::vector<Row>> part(sa_host_threads());
+    const unsigned maxT = sa_host_threads();
+    std::vector<const char*> from(maxT + 1, stop);
+    std::vector<size_t> count(maxT + 1, 0);
     const unsigned T = sa_parallel_for(bytes, 1 << 22, [&](uint64_t lo, uint64_t hi, unsigned th) {
-        // a slice owns the lines that begin in it: move both ends forward to the next line start
         const char* a = body + lo;
         const char* b = body + hi;
         if (lo) { while (a < stop && a[-1] != '\n' && a[-1] != '\r') a++; }
         if (hi < bytes) { while (b < stop && b[-1] != '\n' && b[-1] != '\r') b++; }
-        parse(a, b, part[th]);
+        from[th] = a;
+        count[th] = parse(a, b, nullptr);
     });
-    if (T == 1) { t.rows.swap(part[0]); return SA_OK; }
-    size_t n = 0;
+    from[T] = stop;
     std::vector<size_t> base(T + 1, 0);
-    for (unsigned k = 0; k < T; k++) { n += part[k].size(); base[k + 1] = n; }
-    t.rows.resize(n);
+    for (unsigned k = 0; k < T; k++) base[k + 1] = base[k] + count[k];
+    t.nrows = base[T];
+    t.rows_data = (Row*)malloc(std::max<size_t>(1, t.nrows) * sizeof(Row));
+    if (!t.rows_data) { err = "out of memory for the row table"; return SA_ERR_NOMEM; }
     sa_parallel_for(T, 1, [&](uint64_t lo, uint64_t hi, unsigned) {
-        for (uint64_t k = lo; k < hi; k++)
-            if (!part[k].empty()) memcpy(&t.rows[base[k]], part[k].data(), part[k].size() * sizeof(Row));
+        for (uint64_t k = lo; k < hi; k++) parse(from[k], from[k + 1], t.rows_data + base[k]);
     });
+    t.rows = Table::RowView{t.rows_data, t.nrows};
     return SA_OK;
 }
 
@@ -387,8 +404,12 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
     rep->rows = n;
 
     // encode + validate (the reference has undefined behaviour here; see include/scoring.h:42, include/csv.h:174,181)
-    std::vector<uint64_t> offs(n);
-    std::vector<uint32_t> lens(n);
+    // plain arrays: a vector would clear 150 MB on one thread before the threads below fill them
+    std::unique_ptr<uint64_t[]> offs_mem(new (std::nothrow) uint64_t[n + 1]);
+    std::unique_ptr<uint32_t[]> lens_mem(new (std::nothrow) uint32_t[n + 1]);
+    if (!offs_mem || !lens_mem) { err = "out of memory"; cleanup(); if (out_fd >= 0) close(out_fd); return fail(SA_ERR_NOMEM); }
+    uint64_t* const offs = offs_mem.get();
+    uint32_t* const lens = lens_mem.get();
     uint64_t total = 0;
     for (uint64_t s = 0; s < n; s++) {
         const Row& r = tab.rows[s];
@@ -399,11 +420,13 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
         }
         offs[s] = total; lens[s] = r.len; total += r.len;
     }
-    std::vector<uint8_t> codes(total + 1);
+    std::unique_ptr<uint8_t[]> codes_mem(new (std::nothrow) uint8_t[total + 1]);
+    if (!codes_mem) { err = "out of memory"; cleanup(); if (out_fd >= 0) close(out_fd); return fail(SA_ERR_NOMEM); }
+    uint8_t* const codes = codes_mem.get();
     std::atomic<uint64_t> bad_row(UINT64_MAX);
     sa_parallel_for(n, 1 << 15, [&](uint64_t lo, uint64_t hi, unsigned) {
         for (uint64_t s = lo; s < hi; s++)
-            if (sa_encode(tab.rows[s].seq, lens[s], codes.data() + offs[s]) != SA_OK) {
+            if (sa_encode(tab.rows[s].seq, lens[s], codes + offs[s]) != SA_OK) {
                 uint64_t seen = bad_row.load();
                 while (s < seen && !bad_row.compare_exchange_weak(seen, s)) {}
                 return;
@@ -421,7 +444,7 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
     if (n >= 2) {
         const double tu0 = now_s();
         for (int d = 0; d < ndev; d++) {
-            rc = sa_upload(ctx[(size_t)d], codes.data(), offs.data(), lens.data(), n);
+            rc = sa_upload(ctx[(size_t)d], codes, offs, lens, n);
             if (rc) { cleanup(); if (out_fd >= 0) close(out_fd); return fail(rc); }
         }
         const bool text_mode = st->mode_write && st->device_format;
