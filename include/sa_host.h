@@ -42,7 +42,7 @@ typedef struct {
     int32_t num_devices;              /* GPUs to use, chunks are dealt to them in turn */
     int32_t devices[8];
     int32_t format_threads;           /* host threads that expand and format records; 0 = min(16, cores) */
-    uint64_t pairs_per_submit;        /* 0 = batch_size * 4 */
+    uint64_t pairs_per_submit;        /* 0 = batch_size * 4 (ADJACENT), batch_size * 64 (TRIANGULAR) */
     int32_t pairing;                  /* sa_set_pairing() of every context; default 1 */
     int32_t device_format;            /* 1 (default): rows of CSV text are written on the GPU (sa_submit_text); 0: records come back and host threads format them */
 } sa_settings;

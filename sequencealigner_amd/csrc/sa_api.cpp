@@ -101,6 +101,7 @@ struct Work {                 // one submitted (or prepared) row range
     // text submissions: row lengths, row offsets, text, total bytes, scan scratch; pinned total and text
     DevBuf lens, offs, text, total, scan_tmp;
     PinBuf host_total;
+    PinBuf items_pin;          // the work list on its way to the device (pinned: the copy needs no wait)
     bool text_mode = false;
 };
 
@@ -423,11 +424,13 @@ int prepare_work(sa_ctx* c, Work& w, int schedule, uint64_t r0, uint64_t r1, boo
     if ((rc = w.items.reserve(std::max<size_t>(16, items.size() * sizeof(SaItem))))) return rc;
     if ((rc = w.out.reserve(std::max<size_t>(16, w.npairs * (size_t)c->stride)))) return rc;
     if (need_host && (rc = w.host.reserve(std::max<size_t>(16, w.npairs * (size_t)c->stride)))) return rc;
-    if (!items.empty())
-        SA_HIP_TRY(hipMemcpyAsync(w.items.p, items.data(), items.size() * sizeof(SaItem),
-                                  hipMemcpyHostToDevice, c->compute));
-    // the item vector is pageable memory: the copy must have consumed it before it goes away
-    SA_HIP_TRY(hipStreamSynchronize(c->compute));
+    if (!items.empty()) {
+        // through a pinned buffer of the slot: the copy is queued behind the previous submission's kernels
+        // without the host waiting for them (the slot is reused only after its own kernels are done)
+        if ((rc = w.items_pin.reserve(items.size() * sizeof(SaItem)))) return rc;
+        memcpy(w.items_pin.p, items.data(), items.size() * sizeof(SaItem));
+        SA_HIP_TRY(hipMemcpyAsync(w.items.p, w.items_pin.p, items.size() * sizeof(SaItem), hipMemcpyHostToDevice, c->compute));
+    }
     return SA_OK;
 }
 
@@ -442,7 +445,7 @@ int init_events(Work& w) {
 void free_work(Work& w) {
     w.items.release(); w.out.release(); w.counter.release(); w.host.release();
     w.lens.release(); w.offs.release(); w.text.release(); w.total.release(); w.scan_tmp.release();
-    w.host_total.release();
+    w.host_total.release(); w.items_pin.release();
     if (w.kernel_done) (void)hipEventDestroy(w.kernel_done);
     if (w.copied) (void)hipEventDestroy(w.copied);
     if (w.t0) (void)hipEventDestroy(w.t0);

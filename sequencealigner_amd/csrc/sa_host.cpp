@@ -476,7 +476,11 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
         const uint32_t row_bytes = sa_record_row_bytes(ctx[0]);
 
         // chunks of whole schedule rows; chunk k goes to device k % ndev, results are consumed in chunk order
-        uint64_t cap = st->pairs_per_submit ? st->pairs_per_submit : (uint64_t)st->batch_size * 4;   // 262144 at the default BATCH_SIZE: the best of the tuner's sweep with writing on
+        // 262144 pairs at the default BATCH_SIZE: the best of the tuner's sweep (ADJACENT, writing on).  TRIANGULAR
+        // submissions are whole rows of the schedule and find partners for the paired kernel inside a
+        // submission: sixteen times as many pairs.
+        uint64_t cap = st->pairs_per_submit ? st->pairs_per_submit
+                                            : (uint64_t)st->batch_size * (st->schedule == SA_SCHEDULE_TRIANGULAR ? 64 : 4);
         // text submissions keep a worst-case text buffer per pair on the device: at most about 1 GiB per submission
         if (text_mode) cap = std::min<uint64_t>(cap, std::max<uint64_t>(1024, (1ull << 30) / (6ull * st->max_seq_len + 600)));
         if (cap < 1) cap = 1;
