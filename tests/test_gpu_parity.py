@@ -465,3 +465,27 @@ def test_host_formatting_path_on_the_reference_data_set(tmp_path, schedule, key)
     out = tmp_path / "out.csv"
     sa.run_csv(os.path.join(os.path.dirname(__file__), "golden", "avpdb.csv"), str(out), schedule, device_format=0)
     assert sha256_file(str(out)) == HASHES[key]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("device_format", [1, 0])
+@pytest.mark.parametrize("schedule", [sa.ADJACENT, sa.TRIANGULAR])
+@pytest.mark.parametrize(
+    "text",
+    [
+        b"sequence,label\nACDEF,0\nACDF,1\n",                          # one pair
+        b"sequence,label\nA,0\nW,1\nA,0",                              # single residues, no final newline
+        b"sequence,label\r\nACDEFGHIK,0\r\nMKV,1\r\nMKVACD,1\r\n",    # CR LF line ends
+        b"sequence,label\n\n  ACDEF,0\n\nGHIKL,1\nMFPST,0\n\n",        # blank lines and leading blanks
+        b"sequence,label\nACDEFGHIKL,0\n",                             # one row: no pairs, header only
+    ],
+)
+def test_small_and_ragged_files_in_both_formatting_modes(tmp_path, text, schedule, device_format):
+    """What the reference's parser accepts (include/csv.h:143-209): blank lines, leading blanks, CR LF, a missing
+    final newline.  Rows on the GPU and rows on the host, against the checker."""
+    src = tmp_path / "in.csv"
+    src.write_bytes(text)
+    want, got = tmp_path / "oracle.csv", tmp_path / "gpu.csv"
+    oracle_lib.run_file(str(src), str(want), schedule, threads=2)
+    sa.run_csv(str(src), str(got), schedule, device_format=device_format)
+    assert got.read_bytes() == want.read_bytes()
