@@ -49,10 +49,10 @@ def measured_traffic(kernel, workload):
 
 WORKLOADS = {
     # name: (n, lo, hi, seed, description)
-    "peptides50k": (50000, 6, 50, 1, "synthetic 50k peptides len 6-50 seed 1, all-vs-all (BASELINE configs[2])"),
+    "peptides50k": (50000, 6, 50, 1, "synthetic 50k peptides len 6-50 seed 1, all-vs-all (BASELINE.json configs[2])"),
     "peptides20k": (20000, 6, 50, 1, "synthetic 20k peptides len 6-50 seed 1, all-vs-all"),
     "peptides4k": (4000, 6, 50, 1, "synthetic 4k peptides len 6-50 seed 1, all-vs-all"),
-    "proteins10k": (10000, 300, 1000, 2, "synthetic 10k proteins len 300-1000 seed 2, all-vs-all (BASELINE configs[4])"),
+    "proteins10k": (10000, 300, 1000, 2, "synthetic 10k proteins len 300-1000 seed 2, all-vs-all (BASELINE.json configs[4])"),
     "proteins2k": (2000, 300, 1000, 2, "first 2000 of the synthetic proteins len 300-1000 seed 2, all-vs-all"),
 }
 
@@ -115,7 +115,7 @@ def cpu_baseline(seqs, labels, sample_n):
 
 def side_measurement(name, device):
     """A second workload measured after the timed region (not part of `value`): the
-    long-sequence kernel on a prefix of the protein set of BASELINE configs[4]."""
+    long-sequence kernel on a prefix of the protein set of BASELINE.json configs[4]."""
     n, lo, hi, seed, desc = WORKLOADS[name]
     seqs, _ = synth.generate(n, lo, hi, seed)
     al = sa.Aligner(device=device, max_seq_len=hi)

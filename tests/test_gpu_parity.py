@@ -219,7 +219,7 @@ def test_tuning_knobs_do_not_change_results():
 
 
 def test_full_size_peptide_set_sampled_against_oracle():
-    """BASELINE config 3 at full size (50 000 peptides, 1.25e9 pairs): every record
+    """BASELINE.json configs[2] at full size (50 000 peptides, 1.25e9 pairs): every record
     is produced on the GPU; a random sample and the two ends are checked in full."""
     seqs, _ = synth.generate(50000, 6, 50, seed=1)
     al = sa.Aligner()
