@@ -70,6 +70,15 @@ class Settings(C.Structure):
     ]
 
 
+TEXT_NONE, TEXT_SEQ1, TEXT_SEQ2, TEXT_SCORE, TEXT_ALIGN, TEXT_MATCHES, TEXT_MISMATCHES, TEXT_GAPS, TEXT_SIMILARITY, \
+    TEXT_OTHER1, TEXT_OTHER2 = range(11)
+
+
+class TextLayout(C.Structure):
+    """Mirror of sa_text_layout (include/sa_hip.h)."""
+    _fields_ = [("ncols", C.c_uint32), ("kind", C.c_int8 * 32), ("align_fmt", C.c_char * 128)]
+
+
 class RunReport(C.Structure):
     _fields_ = [
         ("rows", C.c_uint64),
@@ -115,7 +124,7 @@ SIGNATURES = {
     "sa_set_text_layout": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sa_upload_passthrough": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.c_uint64]),
     "sa_submit_text": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64]),
-    "sa_next_text": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "sa_next_text": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "sa_expand_record": (
         C.c_int,
         [_u8p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_char_p, C.c_char_p,
@@ -302,6 +311,47 @@ class Aligner:
         self.submit(schedule, r0, r1)
         rec, _ = self.next()
         out = rec.copy()
+        self.release()
+        return out
+
+    # -- rows of CSV text written on the GPU
+    def set_text_layout(self, kinds, align_fmt="\"('%s', '%s')\""):
+        """kinds: one TEXT_* per output column; align_fmt: the alignment column's format with two %s."""
+        lay = TextLayout()
+        lay.ncols = len(kinds)
+        for k, v in enumerate(kinds[:32]):     # a longer list is refused by the library through ncols
+            lay.kind[k] = v
+        lay.align_fmt = align_fmt.encode()
+        _check(self._lib.sa_set_text_layout(self._ctx, C.byref(lay)))
+
+    def upload_passthrough(self, texts):
+        """The pass-through text of every uploaded row (what OTHER1/OTHER2 columns print)."""
+        blob = b"".join(t.encode() if isinstance(t, str) else t for t in texts)
+        offs = (C.c_uint64 * (len(texts) + 1))()
+        at = 0
+        for k, t in enumerate(texts):
+            offs[k] = at
+            at += len(t)
+        offs[len(texts)] = at
+        _check(self._lib.sa_upload_passthrough(self._ctx, blob, offs, len(texts)))
+
+    def submit_text(self, schedule, r0, r1):
+        _check(self._lib.sa_submit_text(self._ctx, schedule, r0, r1))
+
+    def next_text(self):
+        """(address, byte count, first pair, pairs) of the oldest text submission; the text lives in the
+        context and stays valid until the next-but-one next_text, also after release()."""
+        ptr, nbytes, first, n = C.c_void_p(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _check(self._lib.sa_next_text(self._ctx, C.byref(ptr), C.byref(nbytes), C.byref(first), C.byref(n)))
+        return ptr.value, nbytes.value, first.value, n.value
+
+    def align_text(self, schedule, r0=0, r1=None):
+        """Rows [r0, r1) of the schedule as finished CSV text (bytes)."""
+        if r1 is None:
+            r1 = self.rows(schedule)
+        self.submit_text(schedule, r0, r1)
+        ptr, nbytes, _, _ = self.next_text()
+        out = C.string_at(ptr, nbytes) if nbytes else b""
         self.release()
         return out
 

@@ -489,3 +489,50 @@ def test_small_and_ragged_files_in_both_formatting_modes(tmp_path, text, schedul
     oracle_lib.run_file(str(src), str(want), schedule, threads=2)
     sa.run_csv(str(src), str(got), schedule, device_format=device_format)
     assert got.read_bytes() == want.read_bytes()
+
+
+def _text_rows(al, pairs, labels):
+    rows = []
+    for i, j in pairs:
+        a1, a2, r = oracle_lib.align(al.seqs[i], al.seqs[j])
+        a1, a2, s1, s2 = (a.decode() if isinstance(a, bytes) else a for a in (a1, a2, al.seqs[i], al.seqs[j]))
+        sim = "%d.%02d%%" % (r.similarity_bp // 100, r.similarity_bp % 100)
+        rows.append(f"{labels[j]},{r.score},{s1},[{a1}/{a2}],{r.gaps},{sim},{labels[i]},{r.matches},{r.mismatches},{s2}\n")
+    return "".join(rows).encode()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lo,hi", [(3, 64), (65, 300)])
+def test_text_submissions_through_the_c_abi(lo, hi):
+    rng = random.Random(77)
+    seqs = ["".join(rng.choice(ALPHABET) for _ in range(rng.randint(lo, hi))) for _ in range(60)]
+    labels = [("id%d;x" % k) * (k % 3) for k in range(60)]          # some rows carry no pass-through text
+    al = sa.Aligner(max_seq_len=64 if hi <= 64 else 1024)
+    al.upload(seqs)
+    al.set_text_layout([_lib.TEXT_OTHER2, _lib.TEXT_SCORE, _lib.TEXT_SEQ1, _lib.TEXT_ALIGN, _lib.TEXT_GAPS, _lib.TEXT_SIMILARITY,
+                        _lib.TEXT_OTHER1, _lib.TEXT_MATCHES, _lib.TEXT_MISMATCHES, _lib.TEXT_SEQ2], align_fmt="[%s/%s]")
+    al.upload_passthrough(labels)
+    assert al.align_text(sa.ADJACENT) == _text_rows(al, [(k, k + 1) for k in range(59)], labels)
+    assert al.align_text(sa.TRIANGULAR, 10, 14) == _text_rows(al, _tri_pairs(60, 10, 14), labels)
+    assert al.align_text(sa.TRIANGULAR, 7, 7) == b""
+
+    # two submissions in flight; a text handed out stays readable over one further next_text and after release
+    al.submit_text(sa.TRIANGULAR, 0, 3)
+    al.submit_text(sa.TRIANGULAR, 3, 5)
+    with pytest.raises(sa.SaError):
+        al.submit_text(sa.TRIANGULAR, 5, 6)
+    p0, n0, first0, k0 = al.next_text()
+    al.release()
+    p1, n1, first1, k1 = al.next_text()
+    al.release()
+    assert (first0, k0) == (0, 59 + 58 + 57) and (first1, k1) == (59 + 58 + 57, 56 + 55)
+    import ctypes
+    assert ctypes.string_at(p0, n0) == _text_rows(al, _tri_pairs(60, 0, 3), labels)
+    assert ctypes.string_at(p1, n1) == _text_rows(al, _tri_pairs(60, 3, 5), labels)
+    # a records submission is not answered by next_text
+    al.submit(sa.TRIANGULAR, 0, 1)
+    with pytest.raises(sa.SaError):
+        al.next_text()
+    rec, _ = al.next()
+    assert rec.shape[0] == 59
+    al.release()

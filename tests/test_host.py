@@ -41,6 +41,25 @@ def test_compute_fails_loudly_without_device():
         al.prepare_resident(sa.TRIANGULAR, 0, 2)
 
 
+def test_text_layout_validation_needs_no_device():
+    al = sa.Aligner(device=sa.DEVICE_NONE)
+    al.upload(["ARND", "ARNDC", "WWW"])
+    al.set_text_layout([_lib.TEXT_SEQ1, _lib.TEXT_SEQ2, _lib.TEXT_SCORE, _lib.TEXT_ALIGN])
+    with pytest.raises(sa.SaError):
+        al.set_text_layout([])                                      # no columns
+    with pytest.raises(sa.SaError):
+        al.set_text_layout([_lib.TEXT_SCORE] * 33)                  # more than 32 columns
+    with pytest.raises(sa.SaError):
+        al.set_text_layout([_lib.TEXT_OTHER2 + 1])                  # unknown column kind
+    with pytest.raises(sa.SaError):
+        al.set_text_layout([_lib.TEXT_ALIGN], align_fmt="(%s)")     # the format needs two %s
+    al.set_text_layout([_lib.TEXT_ALIGN], align_fmt="%s|%s")        # empty head and tail are fine
+    with pytest.raises(sa.SaError):
+        al.upload_passthrough(["a", "b", "c"])                      # device-side state: no device, no upload
+    with pytest.raises(sa.SaError):
+        al.submit_text(sa.TRIANGULAR, 0, 2)
+
+
 def test_encode_rejects_non_alphabet():
     lib = sa.load_library()
     buf = (C.c_uint8 * 8)()
