@@ -11,11 +11,13 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Wall -Wno-unused-functi
 all: lib oracle
 
 MAIN    := sequencealigner_amd/sa_main
-TOOLS   := sequencealigner_amd/sa_tune sequencealigner_amd/sa_dataset
+TOOLS   := sequencealigner_amd/sa_tune sequencealigner_amd/sa_dataset sequencealigner_amd/sa_pk_max3_check
 
 lib: $(LIB) $(MAIN) $(TOOLS)
 sequencealigner_amd/sa_tune: $(CSRC)/sa_tune.cpp $(LIB)
 	$(HIPCC) -O2 -std=c++17 -Wall -o $@ $(CSRC)/sa_tune.cpp -Lsequencealigner_amd -lsa_hip -Wl,-rpath,'$$ORIGIN'
+sequencealigner_amd/sa_pk_max3_check: $(CSRC)/sa_pk_max3_check.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -Wno-unused-result -o $@ $(CSRC)/sa_pk_max3_check.hip
 sequencealigner_amd/sa_dataset: $(CSRC)/sa_dataset.c
 	gcc -O2 -Wall -Wextra -o $@ $(CSRC)/sa_dataset.c
 $(MAIN): $(CSRC)/sa_main.cpp $(LIB)

@@ -64,10 +64,14 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
             const int a2 = has2 ? (int)P.codes_fo[(size_t)p2 * SA_LP + lane] : SA_PAD_CODE;
             __syncthreads();   // previous item's readers are done with prof/emask
 #pragma unroll
-            for (int b = 0; b < 20; b++)
-                prof[b * SA_PROF_STRIDE + lane] = SA_PK_TABLE(P.sprime[a1 * SA_SPRIME_STRIDE + b]) |
-                                                  (SA_PK_TABLE(P.sprime[a2 * SA_SPRIME_STRIDE + b]) << 16);
-            prof[20 * SA_PROF_STRIDE + lane] = SA_PK_TABLE(0) | (SA_PK_TABLE(0) << 16);
+            for (int b = 0; b < 20; b++) {
+                // padding scores 1 instead of 0 (an odd column's table entry must stay positive); padded cells
+                // lie to the right of and below every cell that is read
+                const int s1 = max(P.sprime[a1 * SA_SPRIME_STRIDE + b], 1), s2 = max(P.sprime[a2 * SA_SPRIME_STRIDE + b], 1);
+                prof[b * SA_PROF_STRIDE + lane] = (lane & 1) ? SA_NB_TABLE_B(s1) | (SA_NB_TABLE_B(s2) << 16)
+                                                             : SA_NB_TABLE_A(s1) | (SA_NB_TABLE_A(s2) << 16);
+            }
+            prof[20 * SA_PROF_STRIDE + lane] = (lane & 1) ? SA_NB_TABLE_B(1) * 0x10001 : SA_NB_TABLE_A(1) * 0x10001;
 #pragma unroll
             for (int b = 0; b < 20; b++) {
                 const uint64_t m1 = __ballot(a1 == b), m2 = __ballot(a2 == b);
@@ -109,7 +113,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
             // -------------------------------------------------------------- fill
             uint32_t R[NC], Q[NC];
 #pragma unroll
-            for (int c = 0; c < NC; c++) { R[c] = SA_PK_UP; Q[c] = SA_PK_UP; }
+            for (int c = 0; c < NC; c++) { R[c] = Q[c] = (c & 1) ? SA_NB_UP_B : SA_NB_UP_A; }
             uint32_t e[NACC];
 #pragma unroll
             for (int w = 0; w < NACC; w++) e[w] = 0;
@@ -132,15 +136,12 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
             // direction row of one pair: dword k = columns 16k .. 16k+15, column 16k+i at bits 2(15-i)
             auto store_dirs = [&](int r, int g) {
                 const int wr = (g + 3) >> 2;
-                const int half_word = (g & 1) ? (g - 1) >> 1 : -1;     // index of a half-full direction word, if any
                 const int row_off = r * 256 * wpr;
                 uint32_t lo[4], hi[4];
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    // a last word that took only four columns moves them up to where the first four of a full word sit
-                    uint32_t w0 = 0, w1 = 0;
-                    if (2 * k < NACC) w0 = e[(2 * k < NACC) ? 2 * k : 0] << ((half_word == 2 * k) ? 8 : 0);
-                    if (2 * k + 1 < NACC) w1 = e[(2 * k + 1 < NACC) ? 2 * k + 1 : 0] << ((half_word == 2 * k + 1) ? 8 : 0);
+                    const uint32_t w0 = (2 * k < NACC) ? e[(2 * k < NACC) ? 2 * k : 0] : 0;
+                    const uint32_t w1 = (2 * k + 1 < NACC) ? e[(2 * k + 1 < NACC) ? 2 * k + 1 : 0] : 0;
                     lo[k] = __builtin_amdgcn_perm(w0, w1, 0x05040100u);     // low halves:  w0.lo : w1.lo
                     hi[k] = __builtin_amdgcn_perm(w0, w1, 0x07060302u);     // high halves: w0.hi : w1.hi
                 }
@@ -169,7 +170,8 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
             uint32_t o0, o1;
             asm volatile("s_waitcnt vmcnt(0)\n\tv_mul_u32_u24 %0, %2, %4\n\tv_mul_u32_u24 %1, %3, %4"
                          : "=&v"(o0), "=&v"(o1) : "v"(ra), "v"(rb), "s"(SA_PROF_STRIDE) : "memory");
-            int4 sc0 = *reinterpret_cast<const int4*>(prof + o0);
+            // first table entries of the row to come; two registers sets that take turns, so that none is copied
+            int4 sc0 = *reinterpret_cast<const int4*>(prof + o0), sc1 = sc0;
             for (int r = 0; r < maxlen; r += 2) {
                 const uint32_t b2 = residue(r + 2), b3 = residue(r + 3);
                 // the row's end tests compare this copy of gend where they stand: hoisted out of the loop they
@@ -178,7 +180,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
                 asm volatile("" : "+s"(gr));
                 // every lane stores its direction row, also lanes whose sequence 2 has ended (those rows are never
                 // read): every wave then issues exactly four stores per iteration
-                if (r < lenq) fill_row_pair<NG>(R, Q, gr, SA_PK_UP, 0u, prof + o0, prof + o1, sc0, sc0, e);
+                if (r < lenq) fill_row_pair<NG>(R, Q, gr, SA_NB_UP_B, 0u, prof + o0, prof + o1, sc0, sc1, e);
                 store_dirs(r, gr);
                 // Memory operations finish in the order they were issued: with at most the two direction stores of
                 // the row above still in flight, the two residues requested before them have arrived.  (The
@@ -187,15 +189,15 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
                 uint32_t o2, o3;
                 asm volatile("s_waitcnt vmcnt(2)\n\tv_mul_u32_u24 %0, %2, %4\n\tv_mul_u32_u24 %1, %3, %4"
                              : "=&v"(o2), "=&v"(o3) : "v"(b2), "v"(b3), "s"(SA_PROF_STRIDE) : "memory");
-                if (r + 1 < lenq) fill_row_pair<NG>(Q, R, gr, SA_PK_UP, 0u, prof + o1, prof + o2, sc0, sc0, e);
+                if (r + 1 < lenq) fill_row_pair<NG>(Q, R, gr, SA_NB_UP_B, 0u, prof + o1, prof + o2, sc1, sc0, e);
                 store_dirs(r + 1, gr);
                 o0 = o2; o1 = o3;
             }
-            // banks hold 4*D + 2 per half
+            // banks hold 16*D + a tag field per half
             const uint32_t y1q = pick_packed<NC>(Q, lenp1 - 1), y1r = pick_packed<NC>(R, lenp1 - 1);
             const uint32_t y2q = pick_packed<NC>(Q, max(lenp2, 1) - 1), y2r = pick_packed<NC>(R, max(lenp2, 1) - 1);
-            const int d1 = (int)((((lenq & 1) ? y1q : y1r) & 0xffffu) >> 2);
-            const int d2 = (int)(((lenq & 1) ? y2q : y2r) >> 18);
+            const int d1 = (int)((((lenq & 1) ? y1q : y1r) & 0xffffu) >> SA_NB_SHIFT);
+            const int d2 = (int)(((lenq & 1) ? y2q : y2r) >> (16 + SA_NB_SHIFT));
             __syncthreads();   // direction rows written by this wave are visible to its loads
             SA_PHASE(3);
 

@@ -2,11 +2,15 @@
 // paired kernels (sa_kernels_pair.hip, sa_kernels_long_pair.hip).
 //
 // Every VGPR of the DP row holds the cell of (p1, q) in its low 16 bits and the cell of (p2, q)
-// in its high 16 bits.  Tags: 0 LEFT, 2 UP, 3 DIAG (bank values 4*D + 2, table entries 4*S' + 1):
-// with the newest column in the low bits of a direction word a count-trailing-zeros finds a run
-// of LEFT moves (sa_traceback.h, REV = 1).  Per two cells: add (plain 32-bit: no carry crosses
-// as long as every half stays below 2^15), 2 x v_pk_max_i16, and (tags), shift-or (direction
-// word), and (left operand), or (bank value).
+// in its high 16 bits.  Tags: 0 LEFT, 2 UP, 3 DIAG: with the newest column in the low bits of a
+// direction word a count-trailing-zeros finds a run of LEFT moves (sa_traceback.h, REV = 1).
+//
+// Two cell formats:
+//  * 4*D + tag (SA_CELL_PK; long sequences).  Bank values 4*D + 2, table entries 4*S' + 1.  Per two
+//    cells: add (plain 32-bit: no carry crosses as long as every half stays below 2^15),
+//    2 x v_pk_max_i16, and (tags), shift-or (direction word), and (left operand), or (bank value).
+//  * 16*D + two tag fields (SA_CELL_NB; peptides): see below.  Per four cells: 2 add, 2 three-way
+//    maxima, 4 and/or, 3 for the tags.
 #ifndef SA_PAIR_COMMON_H
 #define SA_PAIR_COMMON_H
 
@@ -44,22 +48,75 @@ __device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {
         asm volatile("v_or_b32 %0, 0x20002, %1" : "=v"(OUT[C]) : "v"(zl));               \
     }
 
+// ---- 16*D + two tag fields.
+// Bits 3:2 of a half take the tag of a cell in an even column, bits 1:0 that of a cell in an odd column,
+// so one and + one shift-or move the tags of two columns (times two pairs) into the direction word.
+// The maximum of the three candidates is one instruction, v_pk_maximum3_f16: bit patterns below 0x7c00
+// are the finite non-negative halves (subnormals included, the kernels run with them enabled), which
+// order exactly as the unsigned integers do, and the maximum returns the winning operand unchanged
+// (sa_pk_max3_check.hip compares it with the integer maximum over 10^9 triples).  Hence the range:
+// 16 * 64 * max S' + 15 < 0x7c00, i.e. S' <= 30.
+//  even column a: candidates  diag = bank[a-1] (16*D + 2) + (16*S' + 10) -> field 3:2 = DIAG, field 1:0 = 0
+//                             up   = bank[a]   (16*D + 8)
+//                             left = the raw result of column a-1 (field 3:2 = 0, its own tag in 1:0:
+//                                    the low field never decides between candidates whose high fields differ)
+//  odd column b:  candidates  diag = bank[b-1] (16*D + 8) + (16*S' - 5) = 16*(D + S') + 3: the carry out of
+//                                    the tag fields is taken back by the table entry, hence S' >= 1
+//                             up   = bank[b]   (16*D + 2)
+//                             left = the result of column a with both fields cleared
+// The steps are written as instructions for the reason given above.
+#define SA_NB_UP_A 0x00080008u                       /* bank form of D = 0, even column */
+#define SA_NB_UP_B 0x00020002u                       /* bank form of D = 0, odd column; also diag0 of a border */
+#define SA_NB_TABLE_A(sprime) (16 * (sprime) + 10)   /* table entries for a substitution score S' >= 1 */
+#define SA_NB_TABLE_B(sprime) (16 * (sprime) - 5)
+#define SA_NB_SHIFT 4
+
+// Columns C (even) and C + 1 of both pairs as one block of instructions.  The tags of the two columns go to
+// bits 4(3-i) .. 4(3-i)+3 of each half of the direction word, i = (C mod 8) / 2: a word that takes fewer than
+// eight columns is filled from the top.  The first deposit of a word (a packed 16-bit shift, which also
+// drops the D bits that came along from the odd column) overwrites the word.
+#define SA_NB_HEAD                                                  \
+    "v_pk_maximum3_f16 %[ma], %[ma], %[upa], %[zl]\n\t"             \
+    "v_and_b32 %[la], 0xfff0fff0, %[ma]\n\t"                        \
+    "v_or_b32 %[outa], 0x80008, %[la]\n\t"                          \
+    "v_pk_maximum3_f16 %[mb], %[mb], %[upb], %[la]\n\t"             \
+    "v_bfi_b32 %[t], %[fielda], %[ma], %[mb]\n\t"
+#define SA_NB_TAIL "v_and_or_b32 %[outb], %[mb], %[clean], %[two]"
+#define SA_NB_OPERANDS(ACC_CONSTRAINT, IN, OUT, C, ACC)                                                                      \
+    : [ma] "+v"(ma_), [mb] "+v"(mb_), [la] "=&v"(la_), [t] "=&v"(t_), [outa] "=&v"(OUT[C]),                  \
+      [outb] "=&v"(OUT[(C) + 1]), [acc] ACC_CONSTRAINT(ACC)                                                   \
+    : [upa] "v"(IN[C]), [upb] "v"(IN[(C) + 1]), [zl] "v"(zl), [fielda] "s"(0x000c000cu), [clean] "s"(0xfff0fff0u), \
+      [two] "v"(upb), [low] "s"(0x000f000fu)
+#define SA_CELL_NB(IN, OUT, C, TA, TB, ACC)                                                     \
+    {                                                                                           \
+        uint32_t ma_ = (((C) == 0) ? diag0 : IN[((C) == 0) ? 0 : (C) - 1]) + (uint32_t)(TA);    \
+        uint32_t mb_ = IN[C] + (uint32_t)(TB);                                                  \
+        uint32_t la_, t_;                                                                       \
+        if (((C) & 7) == 0) {                                                                   \
+            asm volatile(SA_NB_HEAD "v_pk_lshlrev_b16 %[acc], 12, %[t] op_sel_hi:[0,1]\n\t" SA_NB_TAIL SA_NB_OPERANDS("=&v", IN, OUT, C, ACC)); \
+        } else if (((C) & 7) == 2) {                                                            \
+            asm volatile(SA_NB_HEAD "v_and_b32 %[t], %[low], %[t]\n\tv_lshl_or_b32 %[acc], %[t], 8, %[acc]\n\t" SA_NB_TAIL SA_NB_OPERANDS("+v", IN, OUT, C, ACC)); \
+        } else if (((C) & 7) == 4) {                                                            \
+            asm volatile(SA_NB_HEAD "v_and_b32 %[t], %[low], %[t]\n\tv_lshl_or_b32 %[acc], %[t], 4, %[acc]\n\t" SA_NB_TAIL SA_NB_OPERANDS("+v", IN, OUT, C, ACC)); \
+        } else {                                                                                \
+            asm volatile(SA_NB_HEAD "v_and_or_b32 %[acc], %[t], %[low], %[acc]\n\t" SA_NB_TAIL SA_NB_OPERANDS("+v", IN, OUT, C, ACC)); \
+        }                                                                                       \
+        zl = mb_;                                                                               \
+    }
+
 // Four columns.  Rows end early: gend = ceil(longer first sequence / 4).
 #define SA_GROUP_PK(G, CUR, NXT)                                                   \
     NXT = *reinterpret_cast<const int4*>(row_base + 4 * ((G) + 1));                \
     __builtin_amdgcn_sched_barrier(0);                                             \
-    SA_CELL_PK(IN, OUT, 4 * (G) + 0, CUR.x, e[(G) >> 1])                           \
-    SA_CELL_PK(IN, OUT, 4 * (G) + 1, CUR.y, e[(G) >> 1])                           \
-    SA_CELL_PK(IN, OUT, 4 * (G) + 2, CUR.z, e[(G) >> 1])                           \
-    SA_CELL_PK(IN, OUT, 4 * (G) + 3, CUR.w, e[(G) >> 1])                           \
+    SA_CELL_NB(IN, OUT, 4 * (G) + 0, CUR.x, CUR.y, e[(G) >> 1])                    \
+    SA_CELL_NB(IN, OUT, 4 * (G) + 2, CUR.z, CUR.w, e[(G) >> 1])                    \
     if (NG == (G) + 1 || gend == (G) + 1) return;
 
-// One packed DP row: IN = previous row, OUT = this row, columns 0 .. 4*gend-1.  diag0 = border value
-// of the previous row in bank form (SA_PK_UP on the matrix border), left0 = this row's border value with
-// the tags cleared (0 on the matrix border).
-// e[w] receives the tags of columns 8w .. 8w+7 of both pairs: column 8w+i at bits
-// 2(7-i) of each 16-bit half -- or, when the row ends after four columns of the word
-// (gend odd), column 8w+i at bits 2(3-i).
+// One packed DP row of 16*D cells: IN = previous row, OUT = this row, columns 0 .. 4*gend-1.  diag0 = border
+// value of the previous row in odd-column bank form (SA_NB_UP_B on the matrix border), left0 = this row's
+// border value with the tags cleared (0 on the matrix border).
+// e[w] receives the tags of columns 8w .. 8w+7 of both pairs: column 8w+i at bits 2(7-i) of each 16-bit
+// half, also when the row ends after four columns of the word.
 template <int NG>
 __device__ __forceinline__ void fill_row_pair(const uint32_t (&IN)[4 * NG], uint32_t (&OUT)[4 * NG], const int gend,
                                               const uint32_t diag0, const uint32_t left0,
@@ -68,6 +125,8 @@ __device__ __forceinline__ void fill_row_pair(const uint32_t (&IN)[4 * NG], uint
                                               uint32_t (&e)[(NG + 1) / 2]) {
     int4 scE = sc_in, scO;
     uint32_t zl = left0;
+    uint32_t upb = SA_NB_UP_B;
+    asm volatile("" : "+v"(upb));          // one register for the whole row, not a copy per use
     sc_out = *reinterpret_cast<const int4*>(next_row_base);
     SA_GROUP_PK(0, scE, scO)
     SA_GROUP_PK(1, scO, scE)

@@ -313,14 +313,32 @@ def test_unpaired_kernel_csv_equals_golden_hash(tmp_path):
 
 @pytest.mark.gpu
 def test_paired_kernel_at_the_edge_of_its_16_bit_range():
-    """S - 2*gap = 120 everywhere a residue matches and 118..120 elsewhere, 64 residues: the largest
-    values the packed cells may hold (4 * 64 * 120 + 3 < 2^15).  One step beyond, the library must
-    take the 32-bit kernel by itself."""
+    """S - 2*gap = 30 everywhere a residue matches and 28..30 elsewhere, 64 residues: the largest values the
+    packed cells may hold (16 * 64 * 30 + 15 is below the first half-precision pattern that is not a finite
+    number).  One step beyond, the library must take the 32-bit kernel by itself."""
     rng = random.Random(5)
     seqs = ["".join(rng.choice(ALPHABET[:4]) for _ in range(rng.choice([64, 64, 63, 50]))) for _ in range(140)]
     n = len(seqs)
-    for top, expect_pairs in ((112, True), (113, False)):
+    for top, expect_pairs in ((22, True), (23, False)):
         matrix = [top if a == b else top - rng.randint(0, 2) for a in range(20) for b in range(20)]
+        al = sa.Aligner(gap=-4, matrix=matrix, max_seq_len=64)
+        al.upload(seqs)
+        items = al.work_items(sa.TRIANGULAR, 0, n - 1).tolist()
+        assert any(it[5] != 0xFFFFFFFF for it in items) == expect_pairs
+        rec = al.align(sa.TRIANGULAR)
+        _check_pairs(al, rec, _tri_pairs(n, 0, n - 1), gap=-4, matrix=matrix)
+
+
+@pytest.mark.gpu
+def test_paired_kernel_at_the_lower_edge_of_its_table_range():
+    """S - 2*gap = 1 for every mismatch (the smallest shifted score the packed cells take: an odd column's table
+    entry takes back a carry and must stay positive) and 30 for a match; with mismatches worth one unit the
+    three candidates tie all the time.  With 0 the library must take the 32-bit kernel."""
+    rng = random.Random(6)
+    seqs = ["".join(rng.choice(ALPHABET[:3]) for _ in range(rng.randint(1, 64))) for _ in range(150)]
+    n = len(seqs)
+    for low, expect_pairs in ((-7, True), (-8, False)):
+        matrix = [22 if a == b else low + (1 if (a + b) % 5 == 0 else 0) for a in range(20) for b in range(20)]
         al = sa.Aligner(gap=-4, matrix=matrix, max_seq_len=64)
         al.upload(seqs)
         items = al.work_items(sa.TRIANGULAR, 0, n - 1).tolist()
@@ -536,3 +554,15 @@ def test_text_submissions_through_the_c_abi(lo, hi):
     rec, _ = al.next()
     assert rec.shape[0] == 59
     al.release()
+
+
+@pytest.mark.gpu
+def test_half_precision_three_way_maximum_orders_like_unsigned_integers():
+    """The paired peptide kernel takes the maximum of its three candidates with v_pk_maximum3_f16 on integer
+    bit patterns below 0x7c00; the check program compares the instruction with the integer maximum on 10^9
+    triples (whole range, near ties, the subnormal range, the top of the range)."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(sa.lib_path()), "sa_pk_max3_check")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=100)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "mismatches 0" in out.stdout

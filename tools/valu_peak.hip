@@ -46,6 +46,10 @@ constexpr int CHAINS = 8;
 #define K_CELL_TAG 27
 #define K_ALIGNBIT 28
 #define K_ANDOR 29
+#define K_PKMAX3F 30
+#define K_BFI 31
+#define K_CELL_PK 32
+#define K_CELL_PK3 33
 
 template <int KIND>
 __global__ void __launch_bounds__(256) k_valu(unsigned* out, unsigned long long* cyc, unsigned seed) {
@@ -119,6 +123,35 @@ __global__ void __launch_bounds__(256) k_valu(unsigned* out, unsigned long long*
             }
             if (KIND == K_ALIGNBIT) asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(a[k]) : "v"(b));
             if (KIND == K_ANDOR) asm volatile("v_and_or_b32 %0, %0, %1, 1" : "+v"(a[k]) : "v"(b));
+            if (KIND == K_PKMAX3F) asm volatile("v_pk_maximum3_f16 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));
+            if (KIND == K_BFI) asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(a[k]) : "v"(b), "v"(c));
+            if (KIND == K_CELL_PK) {
+                // packed 16-bit cells, 2-bit tags: add, 2 x pk_max, and, lshl_or, and, or per two cells
+                unsigned m, h, t;
+                asm volatile("v_add_u32 %0, %1, %2" : "=v"(m) : "v"(a[k]), "v"(b));
+                asm volatile("v_pk_max_i16 %0, %1, %2" : "=v"(h) : "v"(m), "v"(c));
+                asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(h) : "v"(d));
+                asm volatile("v_and_b32 %0, 0x30003, %1" : "=v"(t) : "v"(h));
+                asm volatile("v_lshl_or_b32 %0, %0, 2, %1" : "+v"(f[k]) : "v"(t));
+                asm volatile("v_and_b32 %0, 0xfffcfffc, %1" : "=v"(d) : "v"(h));
+                asm volatile("v_or_b32 %0, 0x20002, %1" : "=v"(a[k]) : "v"(d));
+            }
+            if (KIND == K_CELL_PK3) {
+                // packed cells, 4-bit tag field shared by two columns, three-way half-precision maximum:
+                // 11 instructions per four cells
+                unsigned m, ha, hb, t, la;
+                asm volatile("v_add_u32 %0, %1, %2" : "=v"(m) : "v"(a[k]), "v"(b));
+                asm volatile("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(ha) : "v"(m), "v"(c), "v"(d));
+                asm volatile("v_and_b32 %0, 0xfff0fff0, %1" : "=v"(la) : "v"(ha));
+                asm volatile("v_or_b32 %0, 0x80008, %1" : "=v"(a[k]) : "v"(la));
+                asm volatile("v_add_u32 %0, %1, %2" : "=v"(m) : "v"(g[k]), "v"(b));
+                asm volatile("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(hb) : "v"(m), "v"(c), "v"(la));
+                asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(g[k]) : "v"(hb), "s"(0xfff0fff0u), "v"(b));
+                asm volatile("v_bfi_b32 %0, %1, %2, %3" : "=v"(t) : "s"(0xc000cu), "v"(ha), "v"(hb));
+                asm volatile("v_and_b32 %0, 0xf000f, %1" : "=v"(t) : "v"(t));
+                asm volatile("v_lshl_or_b32 %0, %0, 4, %1" : "+v"(f[k]) : "v"(t));
+                d = hb;
+            }
             if (KIND == K_CELL_SIGN) {
                 // add, max3, (sub, alignbit) x2: direction bits = sign bits of (m - h) and (up - h)
                 unsigned m, h, x, y;
@@ -199,6 +232,10 @@ int main() {
     run<K_CELL_TAG>("cell: add,max3,alignbit,and,or (5)", 5, d_out, d_cyc, ncu);
     run<K_ALIGNBIT>("v_alignbit_b32", 1, d_out, d_cyc, ncu);
     run<K_ANDOR>("v_and_or_b32", 1, d_out, d_cyc, ncu);
+    run<K_PKMAX3F>("v_pk_maximum3_f16", 1, d_out, d_cyc, ncu);
+    run<K_BFI>("v_bfi_b32", 1, d_out, d_cyc, ncu);
+    run<K_CELL_PK>("2 cells: add,2pk_max,and,lshl_or,and,or (7)", 7, d_out, d_cyc, ncu);
+    run<K_CELL_PK3>("4 cells: 2add,2pk_max3,and,or,and_or,bfi,and,lshl_or (10)", 10, d_out, d_cyc, ncu);
     if (getenv("VALU_PEAK_SHORT")) return 0;
     run<K_ADD>("v_add_u32", 1, d_out, d_cyc, ncu);
     run<K_SUB>("v_sub_u32", 1, d_out, d_cyc, ncu);
