@@ -30,17 +30,23 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
     constexpr int NACC = (NG + 1) / 2;
     extern __shared__ __align__(16) uint8_t smem[];
     int32_t* const prof = reinterpret_cast<int32_t*>(smem);
-    uint64_t* const emask = reinterpret_cast<uint64_t*>(smem + SA_LDS_PROF_BYTES);                 // [2][24]
+    // residue codes of the first sequence whose pairs are being traced back: column c at pcol[4 + 2 * c];
+    // pcol[192 + c], pcol[256 + c]: those of the item's two first sequences
+    uint8_t* const pcol = smem + SA_LDS_PROF_BYTES;
     uint32_t* const stage = reinterpret_cast<uint32_t*>(smem + SA_LDS_PROF_BYTES + 2 * SA_LDS_EMASK_BYTES);
     const int lane = threadIdx.x;
+    // the traceback addresses pcol by its offset inside the workgroup's LDS: the dynamic area starts at 0
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t*)smem != 0u) __builtin_trap();
     // rows 0..63 of the spill area hold the direction rows of the low halves, rows 64..127 those of the high halves
     const __amdgpu_buffer_rsrc_t spill = __builtin_amdgcn_make_buffer_rsrc(
         P.spill + (size_t)blockIdx.x * P.spill_rows * 256, 0, P.spill_rows * 1024, SA_BUFFER_FLAGS);
     const __amdgpu_buffer_rsrc_t codes_t = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint8_t*>(P.codes_t), 0, SA_LP * P.npad, SA_BUFFER_FLAGS);
-    // the same descriptor as four scalar words, for the hand-written residue requests
+    // the same descriptors as four scalar words each, for the hand-written requests
     const uint64_t ct_addr = reinterpret_cast<uint64_t>(P.codes_t);
     const sa_u32x4 codes_t_words = {(uint32_t)ct_addr, (uint32_t)(ct_addr >> 32) & 0xffffu, SA_LP * P.npad, SA_BUFFER_FLAGS};
+    const uint64_t sp_addr = reinterpret_cast<uint64_t>(P.spill + (size_t)blockIdx.x * P.spill_rows * 256);
+    const sa_u32x4 spill_words = {(uint32_t)sp_addr, (uint32_t)(sp_addr >> 32) & 0xffffu, P.spill_rows * 1024, SA_BUFFER_FLAGS};
     const uint32_t cpr = P.stride >> 4;   // 16-byte chunks per record
     const bool timed = P.phase_cycles != nullptr;
     unsigned long long tph[6] = {0, 0, 0, 0, 0, 0};
@@ -62,7 +68,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
         {
             const int a1 = P.codes_fo[(size_t)p1 * SA_LP + lane];
             const int a2 = has2 ? (int)P.codes_fo[(size_t)p2 * SA_LP + lane] : SA_PAD_CODE;
-            __syncthreads();   // previous item's readers are done with prof/emask
+            __syncthreads();   // previous item's readers are done with prof/pcol
 #pragma unroll
             for (int b = 0; b < 20; b++) {
                 // padding scores 1 instead of 0 (an odd column's table entry must stay positive); padded cells
@@ -72,12 +78,8 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
                                                              : SA_NB_TABLE_A(s1) | (SA_NB_TABLE_A(s2) << 16);
             }
             prof[20 * SA_PROF_STRIDE + lane] = (lane & 1) ? SA_NB_TABLE_B(1) * 0x10001 : SA_NB_TABLE_A(1) * 0x10001;
-#pragma unroll
-            for (int b = 0; b < 20; b++) {
-                const uint64_t m1 = __ballot(a1 == b), m2 = __ballot(a2 == b);
-                if (lane == b) { emask[b] = m1; emask[24 + b] = m2; }
-            }
-            if (lane == 20) { emask[20] = 0; emask[24 + 20] = 0; }
+            pcol[192 + lane] = (uint8_t)a1;      // kept for the tracebacks: see the loop over the two halves
+            pcol[256 + lane] = (uint8_t)a2;
             __syncthreads();
         }
         const uint64_t n = P.nseq;
@@ -145,16 +147,17 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
                     lo[k] = __builtin_amdgcn_perm(w0, w1, 0x05040100u);     // low halves:  w0.lo : w1.lo
                     hi[k] = __builtin_amdgcn_perm(w0, w1, 0x07060302u);     // high halves: w0.hi : w1.hi
                 }
+                // last dword first (see traceback_pk)
                 if (wr == 4) {
-                    const sa_u32x4 a = {lo[0], lo[1], lo[2], lo[3]}, b = {hi[0], hi[1], hi[2], hi[3]};
+                    const sa_u32x4 a = {lo[3], lo[2], lo[1], lo[0]}, b = {hi[3], hi[2], hi[1], hi[0]};
                     __builtin_amdgcn_raw_buffer_store_b128(a, spill, dir_lane, row_off, 0);
                     __builtin_amdgcn_raw_buffer_store_b128(b, spill, dir_lane, half_off + row_off, 0);
                 } else if (wr == 3) {
-                    const sa_u32x3 a = {lo[0], lo[1], lo[2]}, b = {hi[0], hi[1], hi[2]};
+                    const sa_u32x3 a = {lo[2], lo[1], lo[0]}, b = {hi[2], hi[1], hi[0]};
                     __builtin_amdgcn_raw_buffer_store_b96(a, spill, dir_lane, row_off, 0);
                     __builtin_amdgcn_raw_buffer_store_b96(b, spill, dir_lane, half_off + row_off, 0);
                 } else if (wr == 2) {
-                    const sa_u32x2 a = {lo[0], lo[1]}, b = {hi[0], hi[1]};
+                    const sa_u32x2 a = {lo[1], lo[0]}, b = {hi[1], hi[0]};
                     __builtin_amdgcn_raw_buffer_store_b64(a, spill, dir_lane, row_off, 0);
                     __builtin_amdgcn_raw_buffer_store_b64(b, spill, dir_lane, half_off + row_off, 0);
                 } else {
@@ -170,8 +173,6 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
             uint32_t o0, o1;
             asm volatile("s_waitcnt vmcnt(0)\n\tv_mul_u32_u24 %0, %2, %4\n\tv_mul_u32_u24 %1, %3, %4"
                          : "=&v"(o0), "=&v"(o1) : "v"(ra), "v"(rb), "s"(SA_PROF_STRIDE) : "memory");
-            // first table entries of the row to come; two registers sets that take turns, so that none is copied
-            int4 sc0 = *reinterpret_cast<const int4*>(prof + o0), sc1 = sc0;
             for (int r = 0; r < maxlen; r += 2) {
                 const uint32_t b2 = residue(r + 2), b3 = residue(r + 3);
                 // the row's end tests compare this copy of gend where they stand: hoisted out of the loop they
@@ -180,7 +181,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
                 asm volatile("" : "+s"(gr));
                 // every lane stores its direction row, also lanes whose sequence 2 has ended (those rows are never
                 // read): every wave then issues exactly four stores per iteration
-                if (r < lenq) fill_row_pair<NG>(R, Q, gr, SA_NB_UP_B, 0u, prof + o0, prof + o1, sc0, sc1, e);
+                if (r < lenq) fill_row_pair<NG>(R, Q, gr, SA_NB_UP_B, 0u, prof + o0, e);
                 store_dirs(r, gr);
                 // Memory operations finish in the order they were issued: with at most the two direction stores of
                 // the row above still in flight, the two residues requested before them have arrived.  (The
@@ -189,7 +190,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
                 uint32_t o2, o3;
                 asm volatile("s_waitcnt vmcnt(2)\n\tv_mul_u32_u24 %0, %2, %4\n\tv_mul_u32_u24 %1, %3, %4"
                              : "=&v"(o2), "=&v"(o3) : "v"(b2), "v"(b3), "s"(SA_PROF_STRIDE) : "memory");
-                if (r + 1 < lenq) fill_row_pair<NG>(Q, R, gr, SA_NB_UP_B, 0u, prof + o1, prof + o2, sc1, sc0, e);
+                if (r + 1 < lenq) fill_row_pair<NG>(Q, R, gr, SA_NB_UP_B, 0u, prof + o1, e);
                 store_dirs(r + 1, gr);
                 o0 = o2; o1 = o3;
             }
@@ -217,13 +218,14 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
                 if (!__any(act)) continue;
                 const int lenp = half ? lenp2 : lenp1;
                 const int lq = act ? lenq : 0;
+                reinterpret_cast<uint16_t*>(pcol + 4)[lane] = pcol[192 + 64 * half + lane];
+                __syncthreads();
                 const int mlen = __builtin_amdgcn_readfirstlane(wave_max(lq));
                 const int base = half ? half_off : 0;
-                const uint64_t* em = emask + 24 * half;
                 int matches = 0, gaps = 0;
 #define SA_TRACEBACK(WW)                                                                                   \
-    traceback<SA_MODE_TRI, WW, 1>(lane, mlen, lq, lenp, spill, base, bw, nullptr, nullptr, em,               \
-                                  stage + lane * SA_LDS_STAGE_DWORDS, matches, gaps)
+    traceback_pk<WW, SA_LDS_PROF_BYTES + 4>(lane, mlen, lq, lenp, spill_words, base, bw,                    \
+                                            stage + lane * SA_LDS_STAGE_DWORDS, matches, gaps)
                 if (wpr == 4) SA_TRACEBACK(4);
                 else if (wpr == 3) SA_TRACEBACK(3);
                 else if (wpr == 2) SA_TRACEBACK(2);
@@ -243,8 +245,9 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
                     const uint32_t rrel = __shfl(rel, rec, 64);
                     const int ract = __shfl((int)act, rec, 64);
                     if (ract) {
-                        const uint4 v = *reinterpret_cast<const uint4*>(stage + rec * SA_LDS_STAGE_DWORDS + ch * 4);
-                        *reinterpret_cast<uint4*>(out_row + (uint64_t)rrel * P.stride + ch * 16) = v;
+                        // written once and not read again on the device: kept out of the way of the direction rows
+                        const sa_u32x4 v = *reinterpret_cast<const sa_u32x4*>(stage + rec * SA_LDS_STAGE_DWORDS + ch * 4);
+                        __builtin_nontemporal_store(v, reinterpret_cast<sa_u32x4*>(out_row + (uint64_t)rrel * P.stride + ch * 16));
                     }
                 }
                 __syncthreads();   // staging area is reused

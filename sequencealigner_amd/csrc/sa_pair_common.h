@@ -104,12 +104,16 @@ __device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {
         zl = mb_;                                                                               \
     }
 
-// Four columns.  Rows end early: gend = ceil(longer first sequence / 4).
-#define SA_GROUP_PK(G, CUR, NXT)                                                   \
-    NXT = *reinterpret_cast<const int4*>(row_base + 4 * ((G) + 1));                \
-    __builtin_amdgcn_sched_barrier(0);                                             \
-    SA_CELL_NB(IN, OUT, 4 * (G) + 0, CUR.x, CUR.y, e[(G) >> 1])                    \
-    SA_CELL_NB(IN, OUT, 4 * (G) + 2, CUR.z, CUR.w, e[(G) >> 1])                    \
+// Four columns.  Rows end early: gend = ceil(longer first sequence / 4).  Every group reads its own table
+// entries: a request placed a group ahead is moved by the compiler behind the row's end test, to where its
+// value is used, and hand-placed requests with counted waits gained nothing (the other waves of the SIMD
+// cover the wait).
+#define SA_GROUP_PK(G)                                                             \
+    {                                                                              \
+        const int4 sc_ = *reinterpret_cast<const int4*>(row_base + 4 * (G));       \
+        SA_CELL_NB(IN, OUT, 4 * (G) + 0, sc_.x, sc_.y, e[(G) >> 1])                \
+        SA_CELL_NB(IN, OUT, 4 * (G) + 2, sc_.z, sc_.w, e[(G) >> 1])                \
+    }                                                                              \
     if (NG == (G) + 1 || gend == (G) + 1) return;
 
 // One packed DP row of 16*D cells: IN = previous row, OUT = this row, columns 0 .. 4*gend-1.  diag0 = border
@@ -120,32 +124,13 @@ __device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {
 template <int NG>
 __device__ __forceinline__ void fill_row_pair(const uint32_t (&IN)[4 * NG], uint32_t (&OUT)[4 * NG], const int gend,
                                               const uint32_t diag0, const uint32_t left0,
-                                              const int32_t* __restrict__ row_base,
-                                              const int32_t* __restrict__ next_row_base, const int4& sc_in, int4& sc_out,
-                                              uint32_t (&e)[(NG + 1) / 2]) {
-    int4 scE = sc_in, scO;
+                                              const int32_t* __restrict__ row_base, uint32_t (&e)[(NG + 1) / 2]) {
     uint32_t zl = left0;
     uint32_t upb = SA_NB_UP_B;
     asm volatile("" : "+v"(upb));          // one register for the whole row, not a copy per use
-    sc_out = *reinterpret_cast<const int4*>(next_row_base);
-    SA_GROUP_PK(0, scE, scO)
-    SA_GROUP_PK(1, scO, scE)
-    SA_GROUP_PK(2, scE, scO)
-    SA_GROUP_PK(3, scO, scE)
-    SA_GROUP_PK(4, scE, scO)
-    SA_GROUP_PK(5, scO, scE)
-    SA_GROUP_PK(6, scE, scO)
-    SA_GROUP_PK(7, scO, scE)
-    SA_GROUP_PK(8, scE, scO)
-    SA_GROUP_PK(9, scO, scE)
-    SA_GROUP_PK(10, scE, scO)
-    SA_GROUP_PK(11, scO, scE)
-    SA_GROUP_PK(12, scE, scO)
-    if constexpr (NG > 13) {
-        SA_GROUP_PK(13, scO, scE)
-        SA_GROUP_PK(14, scE, scO)
-        SA_GROUP_PK(15, scO, scE)
-    }
+    SA_GROUP_PK(0) SA_GROUP_PK(1) SA_GROUP_PK(2) SA_GROUP_PK(3) SA_GROUP_PK(4) SA_GROUP_PK(5) SA_GROUP_PK(6)
+    SA_GROUP_PK(7) SA_GROUP_PK(8) SA_GROUP_PK(9) SA_GROUP_PK(10) SA_GROUP_PK(11) SA_GROUP_PK(12)
+    if constexpr (NG > 13) { SA_GROUP_PK(13) SA_GROUP_PK(14) SA_GROUP_PK(15) }
 }
 
 

@@ -166,4 +166,185 @@ __device__ __forceinline__ void traceback(const int lane, const int maxlen, cons
     gaps_out = gaps;
 }
 
+// ---------------------------------------------------------------- traceback, paired peptide kernel
+// The same walk for the REV layout with fewer instructions per row.
+//  * State s = 2 * (columns of sequence 1 still to the left) + 1.  With L = min(trailing zeros of the window, s)
+//    the run of LEFT moves is L & ~1 and the move that ends it is UP when L is odd: a walk that reaches the left
+//    border finds L = s, which is odd.  (On the border itself, s = 1, the shift amount 64 - 2 * columns wraps to
+//    0 and the window holds the unshifted row: there L is forced to 1 by a lower bound, 2 - s, that is negative elsewhere.)  L is
+//    also the output byte (2 * run + up).
+//  * Matches: the first sequence's residue codes lie in LDS two bytes apart (column c at pcol[2c]), so the byte
+//    address of the column a DIAG move consumes is s - L - 3, no shift; on an UP move bit 8 is set in the value
+//    read and the comparison with the row's residue fails.
+//  * The dwords of a direction row are stored last first (dword m = columns 16(W-1-m) .. 16(W-1-m)+15), so that
+//    the register pair a 64-bit load fills is the 64-bit window value, lower columns in the upper half.
+//  * Gaps (the record counts the columns where sequence 1 has '-', the UP moves) are not counted per row but
+//    per chunk: they are the odd bytes of the record.
+__device__ __forceinline__ uint32_t sa_ffbl(uint32_t x) {      // trailing zeros; 0xffffffff for x = 0
+    uint32_t r;
+    asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+__device__ __forceinline__ uint32_t sa_ctz64_sat(uint64_t x) { // trailing zeros of a 64-bit value; >= 64 for x = 0
+    uint32_t fl, fh;
+    asm("v_ffbl_b32 %0, %2\n\tv_ffbl_b32 %1, %3\n\tv_add_u32 %1, %1, 32 clamp"
+        : "=&v"(fl), "=&v"(fh) : "v"((uint32_t)x), "v"((uint32_t)(x >> 32)));
+    return min(fl, fh);
+}
+
+// PCOL_LDS_OFFSET: byte address of column 0's residue code inside the workgroup's LDS (at least 3).
+//  * The direction words of a chunk (four rows) are requested two chunks ahead of their use, as instructions of
+//    their own with hand-counted waits: memory requests complete in the order they were issued, so with the
+//    requests of the two younger chunks allowed to stay in flight ("at most 8 outstanding") the chunk at hand
+//    has arrived.  Left to the compiler, the wait in front of a chunk's first use is for everything in flight,
+//    and the distance shrinks to what one chunk's work covers.
+template <int W> struct SaDirWords;
+template <> struct SaDirWords<1> { typedef uint32_t type; };
+template <> struct SaDirWords<2> { typedef sa_u32x2 type; };
+template <> struct SaDirWords<3> { typedef sa_u32x3 type; };
+template <> struct SaDirWords<4> { typedef sa_u32x4 type; };
+
+template <int W, int PCOL_LDS_OFFSET>
+__device__ __forceinline__ void traceback_pk(const int lane, const int maxlen, const int lenq, const int lenp,
+                                             const sa_u32x4 spill_words, const int base_off,
+                                             uint32_t (&bw)[16],
+                                             uint32_t* __restrict__ stage_rec, int& matches_out, int& gaps_out) {
+    typedef typename SaDirWords<W>::type words_t;
+    struct Chunk { words_t d[4]; };
+    uint32_t s = 2u * (uint32_t)lenp + 1u, matches = 0, ups = 0;
+    const int lane_off = lane * W * 4;
+    // code read for the row processed last and its UP flag, even and odd rows in turn; poisoned to begin with
+    uint32_t pa0 = 0, pa1 = 0, pt0 = 1, pt1 = 1, b4_above = 0;
+
+    // the lane's residue registers are complete before the first hand-counted wait: a wait the compiler places
+    // for them inside the loop would be for everything in flight
+#pragma unroll
+    for (int k = 0; k < 16; k++) asm volatile("" : "+v"(bw[k]));
+
+    // Four requests, always: row indices past the end of the longest sequence are clamped.  (s_nop: the
+    // scalar offset may have been written by a vector instruction just before, see the residue requests.)
+    auto load_chunk = [&](int ch, Chunk& ck) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int r = min(4 * ch + k, maxlen - 1);   // wave-uniform
+            const int row_off = base_off + r * 256 * W;
+            if (W == 4) asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(ck.d[k]) : "v"(lane_off), "s"(spill_words), "s"(row_off) : "memory");
+            else if (W == 3) asm volatile("s_nop 4\n\tbuffer_load_dwordx3 %0, %1, %2, %3 offen" : "+v"(ck.d[k]) : "v"(lane_off), "s"(spill_words), "s"(row_off) : "memory");
+            else if (W == 2) asm volatile("s_nop 4\n\tbuffer_load_dwordx2 %0, %1, %2, %3 offen" : "+v"(ck.d[k]) : "v"(lane_off), "s"(spill_words), "s"(row_off) : "memory");
+            else asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, %3 offen" : "+v"(ck.d[k]) : "v"(lane_off), "s"(spill_words), "s"(row_off) : "memory");
+        }
+    };
+    // chunk `ck` has arrived when at most the requests of the two younger chunks are still in flight
+    auto arrived = [&](Chunk& ck) {
+        asm volatile("s_waitcnt vmcnt(8)" : "+v"(ck.d[0]), "+v"(ck.d[1]), "+v"(ck.d[2]), "+v"(ck.d[3]) : : "memory");
+    };
+
+    auto process = [&](int ch, const Chunk& ck) {
+        const uint32_t b4 = pick_word(bw, ch);
+        uint32_t packed = 0;
+#pragma unroll
+        for (int k = 3; k >= 0; k--) {
+            const int r = 4 * ch + k;
+            if (r < lenq) {
+                const uint32_t sh = 1u - s;                 // (32 or 64) - 2 * columns left, modulo the width of the shift
+                uint32_t L;
+                // lo = 2 - s as a signed number: 1 at the left border (s = 1), where the shift amount has wrapped
+                // round and the window is meaningless, not above 0 elsewhere
+                const int lo = (int)sh + 1;
+                if constexpr (W == 1) {
+                    L = min(sa_ffbl(ck.d[k] >> (sh & 31)), s);
+                } else if constexpr (W == 2) {
+                    const uint64_t v = ((uint64_t)ck.d[k].y << 32) | ck.d[k].x;
+                    L = min(sa_ctz64_sat(v >> (sh & 63)), s);
+                } else {
+                    // columns 0..31 in one 64-bit half, 32..63 in the other; a run that starts in the upper
+                    // half and finds nothing there goes on from column 31
+                    uint64_t v0, v1;
+                    if constexpr (W == 4) {
+                        v0 = ((uint64_t)ck.d[k].w << 32) | ck.d[k].z;
+                        v1 = ((uint64_t)ck.d[k].y << 32) | ck.d[k].x;
+                    } else {
+                        v0 = ((uint64_t)ck.d[k].z << 32) | ck.d[k].y;
+                        v1 = (uint64_t)ck.d[k].x << 32;
+                    }
+                    const bool upper = s > 65u;
+                    const uint32_t lx = sa_ctz64_sat((upper ? v1 : v0) >> (sh & 63));
+                    const uint32_t l0 = sa_ctz64_sat(v0);
+                    L = min((upper && lx >= 64u) ? s - 65u + l0 : lx, s);
+                }
+                L = (uint32_t)max((int)L, lo);
+                // t = L & 1 (1 = UP ends the run, 0 = DIAG); rest = s - L (DIAG: 2 * (column consumed + 1) + 1);
+                // a = pcol[rest - 3]; s = rest + 3t - 2, that is s - run - (2 for a DIAG move); byte k of the
+                // chunk's word = L.  One block of instructions: the LDS address is the state itself plus a
+                // constant that fits the instruction's offset field.  The value read is not waited for here:
+                // the row processed next (the row above) compares it, with bit 8 set when the move was UP, with
+                // the residue of this row -- by then the request before the newest one has arrived (LDS
+                // requests complete in order).  A lane's first row finds the poisoned initial values.  (Every
+                // output is written before the last input is read: none may share a register with an input.)
+                const uint32_t rest = s - L;
+#define SA_TB_ROW(K, ANEW, TNEW, AOLD, TOLD, BOLD, KOLD)                                                     \
+    asm volatile("ds_read_u8 %[an], %[rest] offset:%[off]\n\t"                                               \
+                 "v_and_b32 %[tn], 1, %[L]\n\t"                                                              \
+                 "v_lshl_or_b32 %[packed], %[L], " #K " * 8, %[packed]\n\t"                                  \
+                 "v_mad_u32_u24 %[s], %[tn], 3, %[rest]\n\t"                                                 \
+                 "v_add_u32 %[s], -2, %[s]\n\t"                                                              \
+                 "s_waitcnt lgkmcnt(1)\n\t"                                                                  \
+                 "v_lshl_or_b32 %[ao], %[to], 8, %[ao]\n\t"                                                  \
+                 "v_cmp_eq_u32_sdwa vcc, %[ao], %[bo] src0_sel:DWORD src1_sel:BYTE_" #KOLD "\n\t"            \
+                 "v_addc_co_u32 %[m], vcc, 0, %[m], vcc"                                                     \
+                 : [an] "+&v"(ANEW), [tn] "+&v"(TNEW), [ao] "+&v"(AOLD), [packed] "+&v"(packed),             \
+                   [s] "=&v"(s), [m] "+&v"(matches)                                                          \
+                 : [to] "v"(TOLD), [bo] "v"(BOLD), [rest] "v"(rest), [L] "v"(L),                             \
+                   [off] "n"(PCOL_LDS_OFFSET - 3)                                                            \
+                 : "vcc")
+                if (k == 3) SA_TB_ROW(3, pa1, pt1, pa0, pt0, b4_above, 0);
+                else if (k == 2) SA_TB_ROW(2, pa0, pt0, pa1, pt1, b4, 3);
+                else if (k == 1) SA_TB_ROW(1, pa1, pt1, pa0, pt0, b4, 2);
+                else SA_TB_ROW(0, pa0, pt0, pa1, pt1, b4, 1);
+#undef SA_TB_ROW
+            }
+        }
+        b4_above = b4;
+        ups += __builtin_popcount(packed & 0x01010101u);
+        stage_rec[2 + ch] = packed;
+    };
+
+    // Three sets of registers take turns: step i requests chunk top - i into set i mod 3 and works on chunk
+    // top - i + 2, requested two steps earlier.  Every set is requested at one place and used at one place, and
+    // every statement that touches it reads and writes it in place: a value on its way from memory must not be
+    // copied to another register by the compiler, which does not know that it is still to come.  Requests are
+    // always issued (chunk indices below 0 are clamped to 0), so that the count in arrived() is the same for
+    // every chunk; what is left in flight is drained after the loop, before the registers get another use.
+    Chunk c0, c1, c2;
+#pragma unroll
+    for (int k = 0; k < 4; k++) asm volatile("" : "=v"(c0.d[k]), "=v"(c1.d[k]), "=v"(c2.d[k]));
+    const int top = (maxlen - 1) >> 2;
+    for (int t = top; t >= -2; t -= 3) {
+        load_chunk(max(t, 0), c0);
+        if (t + 2 <= top) { arrived(c1); process(t + 2, c1); }
+        if (t >= -1) {
+            load_chunk(max(t - 1, 0), c1);
+            if (t + 1 <= top) { arrived(c2); process(t + 1, c2); }
+        }
+        if (t >= 0) {
+            load_chunk(max(t - 2, 0), c2);
+            arrived(c0);
+            process(t, c0);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(c0.d[k]), "+v"(c1.d[k]), "+v"(c2.d[k]) : : "memory");
+    // the comparison row 0 left behind (read into the even-row pair)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                 "v_lshl_or_b32 %[ao], %[to], 8, %[ao]\n\t"
+                 "v_cmp_eq_u32_sdwa vcc, %[ao], %[bo] src0_sel:DWORD src1_sel:BYTE_0\n\t"
+                 "v_addc_co_u32 %[m], vcc, 0, %[m], vcc"
+                 : [ao] "+v"(pa0), [m] "+v"(matches) : [to] "v"(pt0), [bo] "v"(b4_above) : "vcc");
+    // body bytes past the last chunk are zero, so that equal inputs give equal records
+    for (int z = ((maxlen - 1) >> 2) + 1; z < SA_LDS_STAGE_DWORDS - 2; z++) stage_rec[2 + z] = 0;
+    matches_out = (int)matches;
+    gaps_out = (int)ups;
+}
+
 #endif
