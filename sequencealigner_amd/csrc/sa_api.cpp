@@ -119,7 +119,7 @@ struct sa_ctx {
     uint32_t wg_per_cu = 13;     // 12 are resident (3 waves per SIMD); one more per CU waits and fills the tail
     bool pairing = true;               // TRIANGULAR peptides: two first sequences per wave where the table allows it
     bool table_fits_i16 = false;       // 1 <= S' <= 30: the packed 16-bit cells of the peptide kernel stay in range
-    bool table_fits_long = false;      // 0 <= S' <= 48: the same for the long-sequence paired kernel
+    bool table_fits_long = false;      // 1 <= S' <= 24: the same for the long-sequence paired kernel
     uint32_t bucket_width = 1;
     // sequences (host mirror)
     uint64_t nseq = 0;
@@ -159,9 +159,9 @@ uint64_t tri_row_start(uint64_t n, uint64_t i) { return i * (2 * n - i - 1) / 2;
 
 // The paired peptide kernel keeps 16*D + 15 below 0x7c00 in 16 bits with D <= 64 * max S' (S' = S - 2*gap,
 // 64 = longest peptide) and takes a carry back through its table entries: it needs 1 <= S' <= 30.
-// The long-sequence paired kernel keeps 4*(D minus a per-lane base) + 3, the base following the strip's
-// border column and moved every 64 rows: a register holds at most 4 * 129 * max S' + 3, which needs
-// 0 <= S' <= 48.
+// The long-sequence paired kernel keeps D minus a per-lane base in the same format, the base following the
+// strip's border column and moved every 16 rows: a register holds at most 16 * 81 * max S' + 15, which needs
+// 1 <= S' <= 24.
 bool table_within(const int32_t* S, int32_t gap, int64_t low, int64_t top) {
     for (int k = 0; k < 400; k++) {
         const int64_t sp = (int64_t)S[k] - 2 * (int64_t)gap;
@@ -510,7 +510,7 @@ int sa_init(sa_ctx** out, const int32_t* S, int32_t gap, uint32_t max_seq_len, i
         h->gap = gap;
         h->max_len = max_seq_len;
         h->table_fits_i16 = table_fits_i16(h->S, gap);
-        h->table_fits_long = table_within(h->S, gap, 0, 48);
+        h->table_fits_long = table_within(h->S, gap, 1, 24);
         *out = h;
         return SA_OK;
     }
@@ -529,7 +529,7 @@ int sa_init(sa_ctx** out, const int32_t* S, int32_t gap, uint32_t max_seq_len, i
     c->gap = gap;
     c->max_len = max_seq_len;
     c->table_fits_i16 = table_fits_i16(c->S, gap);
-    c->table_fits_long = table_within(c->S, gap, 0, 48);
+    c->table_fits_long = table_within(c->S, gap, 1, 24);
     int rc = SA_OK;
     do {
         if ((e = hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking)) != hipSuccess) { rc = hip_code(e); break; }

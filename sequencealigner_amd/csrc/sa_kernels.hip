@@ -277,8 +277,9 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_kernel(const Sa
                 const uint32_t rrel = __shfl(rel, rec, 64);
                 const int ract = __shfl((int)active, rec, 64);
                 if (ract) {
-                    const uint4 v = *reinterpret_cast<const uint4*>(stage + rec * SA_LDS_STAGE_DWORDS + ch * 4);
-                    *reinterpret_cast<uint4*>(out_row + (uint64_t)rrel * P.stride + ch * 16) = v;
+                    // written once and not read again on the device: kept out of the way of the direction rows
+                    const sa_u32x4 v = *reinterpret_cast<const sa_u32x4*>(stage + rec * SA_LDS_STAGE_DWORDS + ch * 4);
+                    __builtin_nontemporal_store(v, reinterpret_cast<sa_u32x4*>(out_row + (uint64_t)rrel * P.stride + ch * 16));
                 }
             }
             __syncthreads();   // staging area is reused by the next task

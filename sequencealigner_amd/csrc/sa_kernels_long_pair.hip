@@ -7,11 +7,13 @@
 // beyond 16 bits, but inside one strip it cannot run away from the strip's left border:
 //   D[r][c] - D[r][c-1] <= max S'   and   D[r][c] - D[r-1][c] <= max S',   D monotone both ways,
 // so every lane keeps, per half, a base that follows its border column and the registers hold
-// D - base.  The recurrence only compares the three operands, so a common offset changes
-// neither the winner nor its tag; every 64 rows the base is moved up to the border value of
-// the row above and the difference is subtracted from the register row (64 subtractions per
-// 64 rows).  Between two moves a register holds at most (65 + 64) * max S' (border growth plus
-// growth along the strip): the host uses this kernel only for tables with 0 <= S' <= 48.
+// D - base in the 16*D cell format of the peptide kernel (sa_pair_common.h: two tag fields,
+// three-way half-precision maximum, values below 0x7c00).  The recurrence only compares the
+// three operands, so a common offset changes neither the winner nor its tag; every 16 rows the
+// base is moved up to the border value of the row above and the difference is subtracted from
+// the register row (64 subtractions per 16 rows).  Between two moves a register holds at most
+// 16 * (17 + 64) * max S' + 15 (border growth plus growth along the strip): the host uses this
+// kernel only for tables with 1 <= S' <= 24 (BLOSUM50 with gap -4: 3 .. 23).
 // The border column travels between strips as absolute 32-bit values, one per half.
 #include "sa_pair_common.h"
 #include "sa_traceback.h"
@@ -94,15 +96,19 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_pair_kernel(const 
                     const int a1 = pseq[64 * s + lane], a2 = pseq[P.lslot + 64 * s + lane];
                     __syncthreads();
 #pragma unroll
-                    for (int b = 0; b < 20; b++)
-                        prof[b * SA_PROF_STRIDE + lane] = SA_PK_TABLE(P.sprime[a1 * SA_SPRIME_STRIDE + b]) |
-                                                          (SA_PK_TABLE(P.sprime[a2 * SA_SPRIME_STRIDE + b]) << 16);
-                    prof[20 * SA_PROF_STRIDE + lane] = SA_PK_TABLE(0) | (SA_PK_TABLE(0) << 16);
+                    for (int b = 0; b < 20; b++) {
+                        // padding scores 1 instead of 0 (an odd column's table entry must stay positive); padded
+                        // cells lie to the right of and below every cell that is read
+                        const int s1 = max(P.sprime[a1 * SA_SPRIME_STRIDE + b], 1), s2 = max(P.sprime[a2 * SA_SPRIME_STRIDE + b], 1);
+                        prof[b * SA_PROF_STRIDE + lane] = (lane & 1) ? SA_NB_TABLE_B(s1) | (SA_NB_TABLE_B(s2) << 16)
+                                                                     : SA_NB_TABLE_A(s1) | (SA_NB_TABLE_A(s2) << 16);
+                    }
+                    prof[20 * SA_PROF_STRIDE + lane] = (lane & 1) ? SA_NB_TABLE_B(1) * 0x10001 : SA_NB_TABLE_A(1) * 0x10001;
                     __syncthreads();
                 }
                 uint32_t R[SA_LP], Q[SA_LP];
 #pragma unroll
-                for (int c = 0; c < SA_LP; c++) { R[c] = SA_PK_UP; Q[c] = SA_PK_UP; }     // border row, base 0
+                for (int c = 0; c < SA_LP; c++) { R[c] = Q[c] = (c & 1) ? SA_NB_UP_B : SA_NB_UP_A; }     // border row, base 0
                 uint32_t e[8];
 #pragma unroll
                 for (int w = 0; w < 8; w++) e[w] = 0;
@@ -115,7 +121,6 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_pair_kernel(const 
                 uint32_t* drowA = dirs + ((size_t)s * rows_cap * 64 + lane) * 4;
                 uint32_t* drowB = drowA + half_dirs;
                 const bool first_strip = s == 0, more_strips = s + 1 < nstrips;
-                const int half_word = (gend & 1) ? (gend - 1) >> 1 : -1;     // index of a half-full direction word, if any
 
                 auto residues4 = [&](int r) -> uint32_t {
                     return *reinterpret_cast<const uint32_t*>(bslot + min(r, last_row - 3));
@@ -123,16 +128,17 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_pair_kernel(const 
                 auto border4 = [&](const int4* bin, int r) -> int4 {
                     return first_strip ? make_int4(0, 0, 0, 0) : bin[(size_t)(min(r, last_row - 3) >> 2) * 64];
                 };
-                // (a, b) relative to the bases, as a left operand: 4 * (D - base) in each half
-                auto rel = [&](int a, int b) -> uint32_t { return ((uint32_t)(a - base1) << 2) | ((uint32_t)(b - base2) << 18); };
+                // (a, b) relative to the bases, as a left operand: 16 * (D - base) in each half
+                auto rel = [&](int a, int b) -> uint32_t {
+                    return ((uint32_t)(a - base1) << SA_NB_SHIFT) | ((uint32_t)(b - base2) << (16 + SA_NB_SHIFT));
+                };
                 // every lane stores its direction rows, also lanes whose sequence 2 has ended (never read):
                 // the stores of a block are then the same for every wave and the waits can be counted
                 auto store_dirs = [&](int r) {
                     uint32_t lo[4], hi[4];
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        const uint32_t w0 = e[2 * k] << ((half_word == 2 * k) ? 8 : 0);
-                        const uint32_t w1 = e[2 * k + 1] << ((half_word == 2 * k + 1) ? 8 : 0);
+                        const uint32_t w0 = e[2 * k], w1 = e[2 * k + 1];
                         lo[k] = __builtin_amdgcn_perm(w0, w1, 0x05040100u);     // low halves:  w0.lo : w1.lo
                         hi[k] = __builtin_amdgcn_perm(w0, w1, 0x07060302u);     // high halves: w0.hi : w1.hi
                     }
@@ -143,38 +149,36 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_pair_kernel(const 
                 uint32_t bres = residues4(0);
                 int4 bordA = border4(binA, 0), bordB = border4(binB, 0);
                 int prevA = 0, prevB = 0;                        // border values of the row above the block
-                int4 sc0 = *reinterpret_cast<const int4*>(prof + (bres & 0xff) * SA_PROF_STRIDE), sc1 = sc0;
-#define SA_LP_ROW(IN, OUT, RR, DA, DB, LA, LB, B, BNEXT, SCI, SCO)                                                        \
+#define SA_LP_ROW(IN, OUT, RR, DA, DB, LA, LB, B)                                                                         \
     if ((RR) < lenq)                                                                                                       \
-        fill_row_pair2(IN, OUT, gend, rel(DA, DB) | SA_PK_UP, rel(LA, LB), prof + (B) * SA_PROF_STRIDE,                    \
-                       prof + (BNEXT) * SA_PROF_STRIDE, SCI, SCO, e);                                                      \
+        fill_row_pair<SA_LP / 4, true>(IN, OUT, gend, rel(DA, DB) | SA_NB_UP_B, rel(LA, LB), prof + (B) * SA_PROF_STRIDE, e);    \
     store_dirs(RR);
                 for (int r = 0; r < maxlen; r += 4) {
                     const uint32_t nres = residues4(r + 4);
                     const int4 nbordA = border4(binA, r + 4), nbordB = border4(binB, r + 4);
                     const uint32_t rb0 = bres & 0xff, rb1 = (bres >> 8) & 0xff, rb2 = (bres >> 16) & 0xff, rb3 = bres >> 24;
-                    if ((r & 63) == 0 && r > 0 && !first_strip) {
+                    if ((r & 15) == 0 && r > 0 && !first_strip) {
                         // move the bases up to the border of the row above; the register row (R on a multiple of
                         // four) follows.  Lanes whose sequence 2 has ended keep what they have.
                         const int d1 = (r < lenq) ? prevA - base1 : 0, d2 = (r < lenq) ? prevB - base2 : 0;
-                        const uint32_t dd = ((uint32_t)d1 << 2) | ((uint32_t)d2 << 18);
+                        const uint32_t dd = ((uint32_t)d1 << SA_NB_SHIFT) | ((uint32_t)d2 << (16 + SA_NB_SHIFT));
 #pragma unroll
                         for (int c = 0; c < SA_LP; c++) R[c] -= dd;
                         base1 += d1; base2 += d2;
                     }
-                    SA_LP_ROW(R, Q, r, prevA, prevB, bordA.x, bordB.x, rb0, rb1, sc0, sc1)
+                    SA_LP_ROW(R, Q, r, prevA, prevB, bordA.x, bordB.x, rb0)
                     const uint32_t y0 = Q[SA_LP - 1];
-                    SA_LP_ROW(Q, R, r + 1, bordA.x, bordB.x, bordA.y, bordB.y, rb1, rb2, sc1, sc0)
+                    SA_LP_ROW(Q, R, r + 1, bordA.x, bordB.x, bordA.y, bordB.y, rb1)
                     const uint32_t y1 = R[SA_LP - 1];
-                    SA_LP_ROW(R, Q, r + 2, bordA.y, bordB.y, bordA.z, bordB.z, rb2, rb3, sc0, sc1)
+                    SA_LP_ROW(R, Q, r + 2, bordA.y, bordB.y, bordA.z, bordB.z, rb2)
                     const uint32_t y2 = Q[SA_LP - 1];
-                    SA_LP_ROW(Q, R, r + 3, bordA.z, bordB.z, bordA.w, bordB.w, rb3, (nres & 0xff), sc1, sc0)
+                    SA_LP_ROW(Q, R, r + 3, bordA.z, bordB.z, bordA.w, bordB.w, rb3)
                     const uint32_t y3 = R[SA_LP - 1];
                     if (more_strips) {
-                        boutA[(size_t)(r >> 2) * 64] = make_int4((int)((y0 & 0xffffu) >> 2) + base1, (int)((y1 & 0xffffu) >> 2) + base1,
-                                                                 (int)((y2 & 0xffffu) >> 2) + base1, (int)((y3 & 0xffffu) >> 2) + base1);
-                        boutB[(size_t)(r >> 2) * 64] = make_int4((int)(y0 >> 18) + base2, (int)(y1 >> 18) + base2,
-                                                                 (int)(y2 >> 18) + base2, (int)(y3 >> 18) + base2);
+                        boutA[(size_t)(r >> 2) * 64] = make_int4((int)((y0 & 0xffffu) >> SA_NB_SHIFT) + base1, (int)((y1 & 0xffffu) >> SA_NB_SHIFT) + base1,
+                                                                 (int)((y2 & 0xffffu) >> SA_NB_SHIFT) + base1, (int)((y3 & 0xffffu) >> SA_NB_SHIFT) + base1);
+                        boutB[(size_t)(r >> 2) * 64] = make_int4((int)(y0 >> (16 + SA_NB_SHIFT)) + base2, (int)(y1 >> (16 + SA_NB_SHIFT)) + base2,
+                                                                 (int)(y2 >> (16 + SA_NB_SHIFT)) + base2, (int)(y3 >> (16 + SA_NB_SHIFT)) + base2);
                     }
                     prevA = bordA.w; prevB = bordB.w;
                     bres = nres;
@@ -184,11 +188,11 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_pair_kernel(const 
                 // the scores sit in the strips that hold each half's last column
                 if (((lenp1 - 1) >> 6) == s) {
                     const uint32_t yq = pick_packed<SA_LP>(Q, (lenp1 - 1) & 63), yr = pick_packed<SA_LP>(R, (lenp1 - 1) & 63);
-                    dfin1 = (int)((((lenq & 1) ? yq : yr) & 0xffffu) >> 2) + base1;
+                    dfin1 = (int)((((lenq & 1) ? yq : yr) & 0xffffu) >> SA_NB_SHIFT) + base1;
                 }
                 if (has2 && ((lenp2 - 1) >> 6) == s) {
                     const uint32_t yq = pick_packed<SA_LP>(Q, (lenp2 - 1) & 63), yr = pick_packed<SA_LP>(R, (lenp2 - 1) & 63);
-                    dfin2 = (int)(((lenq & 1) ? yq : yr) >> 18) + base2;
+                    dfin2 = (int)(((lenq & 1) ? yq : yr) >> (16 + SA_NB_SHIFT)) + base2;
                 }
                 __syncthreads();   // border column and direction rows are complete before anyone reads them
             }

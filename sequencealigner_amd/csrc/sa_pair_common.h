@@ -5,50 +5,13 @@
 // in its high 16 bits.  Tags: 0 LEFT, 2 UP, 3 DIAG: with the newest column in the low bits of a
 // direction word a count-trailing-zeros finds a run of LEFT moves (sa_traceback.h, REV = 1).
 //
-// Two cell formats:
-//  * 4*D + tag (SA_CELL_PK; long sequences).  Bank values 4*D + 2, table entries 4*S' + 1.  Per two
-//    cells: add (plain 32-bit: no carry crosses as long as every half stays below 2^15),
-//    2 x v_pk_max_i16, and (tags), shift-or (direction word), and (left operand), or (bank value).
-//  * 16*D + two tag fields (SA_CELL_NB; peptides): see below.  Per four cells: 2 add, 2 three-way
-//    maxima, 4 and/or, 3 for the tags.
+// Cell format: 16*D + two tag fields.  Per four cells (two columns of both pairs): 2 add, 2 three-way
+// maxima, and, or, and-or for the operands of the cells to come, 2.5 on average for the tags.
 #ifndef SA_PAIR_COMMON_H
 #define SA_PAIR_COMMON_H
 
 #include "sa_kernel_common.h"
 
-typedef short sa_i16x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(sa_i16x2, a), __builtin_bit_cast(sa_i16x2, b)));
-}
-
-#define SA_PK_TAGS 0x00030003u
-#define SA_PK_CLEAN 0xfffcfffcu
-#define SA_PK_UP 0x00020002u                         /* bank form of D = 0 in both halves */
-#define SA_PK_TABLE(sprime) (4 * (sprime) + 1)       /* table entry for a substitution score S' */
-
-// One packed cell.  The direction word of eight columns starts afresh at the first of
-// them (nothing is shifted across the 16-bit boundary: a word takes at most eight tags).
-// The tag and bank steps are written as instructions so that they stay where they are:
-// moved to the end of the row by the compiler they keep one more register per column
-// alive, and the row no longer fits the register file.
-#define SA_CELL_PK(IN, OUT, C, T, ACC)                                                   \
-    {                                                                                    \
-        const uint32_t diag_ = ((C) == 0) ? diag0 : IN[((C) == 0) ? 0 : (C) - 1];       \
-        const uint32_t m_ = diag_ + (uint32_t)(T);                                       \
-        const uint32_t h_ = pk_max(pk_max(m_, IN[C]), zl);                               \
-        if (((C) & 7) == 0) {                                                            \
-            asm volatile("v_and_b32 %0, 0x30003, %1" : "=v"(ACC) : "v"(h_));             \
-        } else {                                                                         \
-            uint32_t t_;                                                                 \
-            asm volatile("v_and_b32 %0, 0x30003, %1" : "=v"(t_) : "v"(h_));              \
-            asm volatile("v_lshl_or_b32 %0, %0, 2, %1" : "+v"(ACC) : "v"(t_));           \
-        }                                                                                \
-        zl = h_ & SA_PK_CLEAN;                                                           \
-        asm volatile("v_or_b32 %0, 0x20002, %1" : "=v"(OUT[C]) : "v"(zl));               \
-    }
-
-// ---- 16*D + two tag fields.
 // Bits 3:2 of a half take the tag of a cell in an even column, bits 1:0 that of a cell in an odd column,
 // so one and + one shift-or move the tags of two columns (times two pairs) into the direction word.
 // The maximum of the three candidates is one instruction, v_pk_maximum3_f16: bit patterns below 0x7c00
@@ -64,7 +27,8 @@ __device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {
 //                                    the tag fields is taken back by the table entry, hence S' >= 1
 //                             up   = bank[b]   (16*D + 2)
 //                             left = the result of column a with both fields cleared
-// The steps are written as instructions for the reason given above.
+// The steps are written as instructions so that they stay where they are: moved to the end of the row by the
+// compiler they keep one more register per column alive, and the row no longer fits the register file.
 #define SA_NB_UP_A 0x00080008u                       /* bank form of D = 0, even column */
 #define SA_NB_UP_B 0x00020002u                       /* bank form of D = 0, odd column; also diag0 of a border */
 #define SA_NB_TABLE_A(sprime) (16 * (sprime) + 10)   /* table entries for a substitution score S' >= 1 */
@@ -104,16 +68,29 @@ __device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {
         zl = mb_;                                                                               \
     }
 
-// Four columns.  Rows end early: gend = ceil(longer first sequence / 4).  Every group reads its own table
-// entries: a request placed a group ahead is moved by the compiler behind the row's end test, to where its
-// value is used, and hand-placed requests with counted waits gained nothing (the other waves of the SIMD
-// cover the wait).
-#define SA_GROUP_PK(G)                                                             \
-    {                                                                              \
-        const int4 sc_ = *reinterpret_cast<const int4*>(row_base + 4 * (G));       \
-        SA_CELL_NB(IN, OUT, 4 * (G) + 0, sc_.x, sc_.y, e[(G) >> 1])                \
-        SA_CELL_NB(IN, OUT, 4 * (G) + 2, sc_.z, sc_.w, e[(G) >> 1])                \
+// Four columns.  Rows end early: gend = ceil(longer first sequence / 4).
+// AHEAD = false: every group reads its own table entries and waits for them (a request the source places a
+// group ahead is moved by the compiler behind the row's end test, to where its value is used).  With three waves
+// per SIMD the other waves cover that wait, and hand-placed requests gained nothing.
+// AHEAD = true: the entries of group G + 1 are requested, as an instruction of its own, before the cells of
+// group G, and waited for by count: requests to the LDS complete in the order they were issued, so "at most
+// one outstanding" means that all but the newest have arrived.  The request for the group behind the row's end
+// stays inside the profile row and is never used.  For kernels that run two waves per SIMD.
+typedef int sa_i32x4 __attribute__((ext_vector_type(4)));
+#define SA_LDS_REQUEST(DST, ADDR, BYTES) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(BYTES))
+#define SA_GROUP_PK(G, CUR, NXT)                                                   \
+    if (AHEAD) {                                                                   \
+        if ((G) + 1 < NG) {                                                        \
+            SA_LDS_REQUEST(NXT, row_addr, 16 * ((G) + 1));                         \
+            asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(CUR));                      \
+        } else {                                                                   \
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(CUR));                      \
+        }                                                                          \
+    } else {                                                                       \
+        CUR = *reinterpret_cast<const sa_i32x4*>(row_base + 4 * (G));              \
     }                                                                              \
+    SA_CELL_NB(IN, OUT, 4 * (G) + 0, CUR.x, CUR.y, e[(G) >> 1])                    \
+    SA_CELL_NB(IN, OUT, 4 * (G) + 2, CUR.z, CUR.w, e[(G) >> 1])                    \
     if (NG == (G) + 1 || gend == (G) + 1) return;
 
 // One packed DP row of 16*D cells: IN = previous row, OUT = this row, columns 0 .. 4*gend-1.  diag0 = border
@@ -121,56 +98,23 @@ __device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {
 // border value with the tags cleared (0 on the matrix border).
 // e[w] receives the tags of columns 8w .. 8w+7 of both pairs: column 8w+i at bits 2(7-i) of each 16-bit
 // half, also when the row ends after four columns of the word.
-template <int NG>
+template <int NG, bool AHEAD = false>
 __device__ __forceinline__ void fill_row_pair(const uint32_t (&IN)[4 * NG], uint32_t (&OUT)[4 * NG], const int gend,
                                               const uint32_t diag0, const uint32_t left0,
                                               const int32_t* __restrict__ row_base, uint32_t (&e)[(NG + 1) / 2]) {
     uint32_t zl = left0;
     uint32_t upb = SA_NB_UP_B;
     asm volatile("" : "+v"(upb));          // one register for the whole row, not a copy per use
-    SA_GROUP_PK(0) SA_GROUP_PK(1) SA_GROUP_PK(2) SA_GROUP_PK(3) SA_GROUP_PK(4) SA_GROUP_PK(5) SA_GROUP_PK(6)
-    SA_GROUP_PK(7) SA_GROUP_PK(8) SA_GROUP_PK(9) SA_GROUP_PK(10) SA_GROUP_PK(11) SA_GROUP_PK(12)
-    if constexpr (NG > 13) { SA_GROUP_PK(13) SA_GROUP_PK(14) SA_GROUP_PK(15) }
+    sa_i32x4 scE, scO;
+    const uint32_t row_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const int32_t*)row_base;
+    if (AHEAD) SA_LDS_REQUEST(scE, row_addr, 0);
+    SA_GROUP_PK(0, scE, scO) SA_GROUP_PK(1, scO, scE) SA_GROUP_PK(2, scE, scO) SA_GROUP_PK(3, scO, scE)
+    SA_GROUP_PK(4, scE, scO) SA_GROUP_PK(5, scO, scE) SA_GROUP_PK(6, scE, scO) SA_GROUP_PK(7, scO, scE)
+    SA_GROUP_PK(8, scE, scO) SA_GROUP_PK(9, scO, scE) SA_GROUP_PK(10, scE, scO) SA_GROUP_PK(11, scO, scE)
+    SA_GROUP_PK(12, scE, scO)
+    if constexpr (NG > 13) { SA_GROUP_PK(13, scO, scE) SA_GROUP_PK(14, scE, scO) SA_GROUP_PK(15, scO, scE) }
 }
 
-
-// The same row for 64 columns with the table entries requested two groups ahead (three rotating
-// buffers): for kernels that run two waves per SIMD.
-#define SA_GROUP_PK2(G, CUR, FAR)                                                  \
-    FAR = *reinterpret_cast<const int4*>(row_base + 4 * ((G) + 2));                \
-    __builtin_amdgcn_sched_barrier(0);                                             \
-    SA_CELL_PK(IN, OUT, 4 * (G) + 0, CUR.x, e[(G) >> 1])                           \
-    SA_CELL_PK(IN, OUT, 4 * (G) + 1, CUR.y, e[(G) >> 1])                           \
-    SA_CELL_PK(IN, OUT, 4 * (G) + 2, CUR.z, e[(G) >> 1])                           \
-    SA_CELL_PK(IN, OUT, 4 * (G) + 3, CUR.w, e[(G) >> 1])                           \
-    if ((G) == 15 || gend == (G) + 1) return;
-
-__device__ __forceinline__ void fill_row_pair2(const uint32_t (&IN)[SA_LP], uint32_t (&OUT)[SA_LP], const int gend,
-                                               const uint32_t diag0, const uint32_t left0,
-                                               const int32_t* __restrict__ row_base,
-                                               const int32_t* __restrict__ next_row_base, const int4& sc_in, int4& sc_out,
-                                               uint32_t (&e)[8]) {
-    int4 sA = sc_in, sB, sC;
-    uint32_t zl = left0;
-    sB = *reinterpret_cast<const int4*>(row_base + 4);
-    sc_out = *reinterpret_cast<const int4*>(next_row_base);
-    SA_GROUP_PK2(0, sA, sC)
-    SA_GROUP_PK2(1, sB, sA)
-    SA_GROUP_PK2(2, sC, sB)
-    SA_GROUP_PK2(3, sA, sC)
-    SA_GROUP_PK2(4, sB, sA)
-    SA_GROUP_PK2(5, sC, sB)
-    SA_GROUP_PK2(6, sA, sC)
-    SA_GROUP_PK2(7, sB, sA)
-    SA_GROUP_PK2(8, sC, sB)
-    SA_GROUP_PK2(9, sA, sC)
-    SA_GROUP_PK2(10, sB, sA)
-    SA_GROUP_PK2(11, sC, sB)
-    SA_GROUP_PK2(12, sA, sC)
-    SA_GROUP_PK2(13, sB, sA)
-    SA_GROUP_PK2(14, sC, sB)
-    SA_GROUP_PK2(15, sA, sC)
-}
 
 // value of register column `col` (wave-uniform) of a packed row bank
 #define SA_PICK_PK(C) case C: v = BANK[(C) < NC ? (C) : 0]; break;

@@ -383,13 +383,17 @@ def test_long_paired_and_unpaired_kernels_give_identical_records(n, lo, hi, seed
 
 @pytest.mark.gpu
 def test_long_paired_kernel_at_the_edge_of_its_range():
-    """S - 2*gap up to 48 is the most the long paired kernel takes (registers hold at most 4 * 129 * 48 + 3);
-    one more and the library must use 32-bit cells by itself.  Sequences of one letter reach the largest D."""
+    """S - 2*gap up to 24 is the most the long paired kernel takes (registers hold at most 16 * 81 * 24 + 15,
+    below the first half-precision pattern that is not a finite number); one more and the library must use
+    32-bit cells by itself.  Sequences of one letter reach the largest D.  At the lower edge (1 for a mismatch)
+    the candidates tie all the time; with 0 the 32-bit cells take over."""
     rng = random.Random(9)
     seqs = ["".join(rng.choice("AAAR") for _ in range(rng.choice([400, 333, 256, 129]))) for _ in range(70)]
     n = len(seqs)
-    for top, expect_pairs in ((40, True), (41, False)):
-        matrix = [top if a == b else top - rng.randint(0, 3) for a in range(20) for b in range(20)]
+    # (match score, lowest mismatch score): S' = score + 8
+    for top, worst, expect_pairs in ((16, 13, True), (17, 14, False), (16, -7, True), (16, -8, False)):
+        matrix = [top if a == b else worst + rng.randint(0, 3) for a in range(20) for b in range(20)]
+        matrix[1] = matrix[20] = worst          # A/R, the two letters in use
         al = sa.Aligner(gap=-4, matrix=matrix, max_seq_len=400)
         al.upload(seqs)
         assert any(it[5] != 0xFFFFFFFF for it in al.work_items(sa.TRIANGULAR, 0, n - 1).tolist()) == expect_pairs
