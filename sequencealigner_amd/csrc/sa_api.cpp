@@ -118,8 +118,7 @@ struct sa_ctx {
     uint32_t tiles_per_item = 8;
     uint32_t wg_per_cu = 13;     // 12 are resident (3 waves per SIMD); one more per CU waits and fills the tail
     bool pairing = true;               // TRIANGULAR peptides: two first sequences per wave where the table allows it
-    bool table_fits_i16 = false;       // 1 <= S' <= 30: the packed 16-bit cells of the peptide kernel stay in range
-    bool table_fits_long = false;      // 1 <= S' <= 24: the same for the long-sequence paired kernel
+    int64_t sprime_min = 0, sprime_max = 0;   // range of S' = S - 2*gap over the table: decides whether packed cells fit
     uint32_t bucket_width = 1;
     // sequences (host mirror)
     uint64_t nseq = 0;
@@ -157,19 +156,21 @@ namespace {
 
 uint64_t tri_row_start(uint64_t n, uint64_t i) { return i * (2 * n - i - 1) / 2; }
 
-// The paired peptide kernel keeps 16*D + 15 below 0x7c00 in 16 bits with D <= 64 * max S' (S' = S - 2*gap,
-// 64 = longest peptide) and takes a carry back through its table entries: it needs 1 <= S' <= 30.
-// The long-sequence paired kernel keeps D minus a per-lane base in the same format, the base following the
-// strip's border column and moved every 16 rows: a register holds at most 16 * 81 * max S' + 15, which needs
-// 1 <= S' <= 24.
-bool table_within(const int32_t* S, int32_t gap, int64_t low, int64_t top) {
+// The paired kernels keep 16*D + 15 below 0x7c00 (1983 for D) in 16 bits and take a carry back through their
+// table entries (S' >= 1, S' = S - 2*gap).  Peptides: D <= longest sequence * max S'.  Long sequences: D minus a
+// per-lane base that follows the strip's border column and is moved every 16 rows, at most (17 + 64) * max S'.
+void table_range(const int32_t* S, int32_t gap, int64_t& low, int64_t& top) {
+    low = INT64_MAX; top = INT64_MIN;
     for (int k = 0; k < 400; k++) {
         const int64_t sp = (int64_t)S[k] - 2 * (int64_t)gap;
-        if (sp < low || sp > top) return false;
+        low = std::min(low, sp); top = std::max(top, sp);
     }
-    return true;
 }
-bool table_fits_i16(const int32_t* S, int32_t gap) { return table_within(S, gap, 1, 30); }
+bool packed_cells_fit(const sa_ctx* c, bool lng) {
+    if (c->sprime_min < 1) return false;
+    const int64_t span = lng ? 17 + 64 : std::max<int64_t>(1, std::min<int64_t>(c->max_seq, SA_LP));
+    return span * c->sprime_max <= 1983;
+}
 
 // Bucket order of the sequences and the cursor table (see sa_device.h); TRIANGULAR only.
 void ensure_suffix(sa_ctx* c) {
@@ -248,7 +249,7 @@ int ensure_triangular(sa_ctx* c) {
 bool is_long(const sa_ctx* c) { return c->lslot > SA_LP; }
 
 // TRIANGULAR work of a peptide context runs on the paired kernel (two first sequences per wave)
-bool uses_pairs(const sa_ctx* c) { return c->pairing && (is_long(c) ? c->table_fits_long : c->table_fits_i16); }
+bool uses_pairs(const sa_ctx* c) { return c->pairing && packed_cells_fit(c, is_long(c)); }
 
 // paired (in/out): the caller allows the paired kernel / the items were built for it.  A row range in which
 // fewer than half of the first sequences find a partner of their length bucket runs unpaired: a wave of
@@ -509,8 +510,7 @@ int sa_init(sa_ctx** out, const int32_t* S, int32_t gap, uint32_t max_seq_len, i
         if (S) memcpy(h->S, S, sizeof(h->S)); else sa_default_matrix(h->S);
         h->gap = gap;
         h->max_len = max_seq_len;
-        h->table_fits_i16 = table_fits_i16(h->S, gap);
-        h->table_fits_long = table_within(h->S, gap, 1, 24);
+        table_range(h->S, gap, h->sprime_min, h->sprime_max);
         *out = h;
         return SA_OK;
     }
@@ -528,8 +528,7 @@ int sa_init(sa_ctx** out, const int32_t* S, int32_t gap, uint32_t max_seq_len, i
     if (S) memcpy(c->S, S, sizeof(c->S)); else sa_default_matrix(c->S);
     c->gap = gap;
     c->max_len = max_seq_len;
-    c->table_fits_i16 = table_fits_i16(c->S, gap);
-    c->table_fits_long = table_within(c->S, gap, 1, 24);
+    table_range(c->S, gap, c->sprime_min, c->sprime_max);
     int rc = SA_OK;
     do {
         if ((e = hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking)) != hipSuccess) { rc = hip_code(e); break; }
