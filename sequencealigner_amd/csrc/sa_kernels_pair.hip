@@ -40,11 +40,6 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
     // rows 0..63 of the spill area hold the direction rows of the low halves, rows 64..127 those of the high halves
     const __amdgpu_buffer_rsrc_t spill = __builtin_amdgcn_make_buffer_rsrc(
         P.spill + (size_t)blockIdx.x * P.spill_rows * 256, 0, P.spill_rows * 1024, SA_BUFFER_FLAGS);
-    const __amdgpu_buffer_rsrc_t codes_t = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint8_t*>(P.codes_t), 0, SA_LP * P.npad, SA_BUFFER_FLAGS);
-    // the same descriptors as four scalar words each, for the hand-written requests
-    const uint64_t ct_addr = reinterpret_cast<uint64_t>(P.codes_t);
-    const sa_u32x4 codes_t_words = {(uint32_t)ct_addr, (uint32_t)(ct_addr >> 32) & 0xffffu, SA_LP * P.npad, SA_BUFFER_FLAGS};
     const uint64_t sp_addr = reinterpret_cast<uint64_t>(P.spill + (size_t)blockIdx.x * P.spill_rows * 256);
     const sa_u32x4 spill_words = {(uint32_t)sp_addr, (uint32_t)(sp_addr >> 32) & 0xffffu, P.spill_rows * 1024, SA_BUFFER_FLAGS};
     const uint32_t cpr = P.stride >> 4;   // 16-byte chunks per record
@@ -120,19 +115,22 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
 #pragma unroll
             for (int w = 0; w < NACC; w++) e[w] = 0;
 
-            // Row residue r of the lane's second sequence.  The request is written as an instruction of its own,
-            // outside the compiler's bookkeeping of outstanding memory operations: the compiler would wait for
-            // *everything* in flight before the first use, direction stores included; here the wait is counted by
-            // hand (see the end of the row loop).
-            auto residue = [&](int r) -> uint32_t {
-                uint32_t v;
-                const int soff = min(r, SA_LP - 1) * (int)P.npad;
-                // s_nop 4: the scalar operands may have been written by a vector instruction just before (a restored
-                // register, v_readlane): a memory instruction needs five wait states after that, and the compiler
-                // does not insert them for instructions it cannot see into
-                asm volatile("s_nop 4\n\tbuffer_load_ubyte %0, %1, %2, %3 offen" : "=v"(v) : "v"(sidx), "s"(codes_t_words), "s"(soff) : "memory");
-                return v;
-            };
+            // The lane's second sequence goes to its part of the staging area (bytes 8 .. 71, where the record's
+            // row bytes will stand): the row loop then reads its residues from the LDS and contains no memory
+            // loads, so nothing in it waits for the direction stores to be acknowledged.  (With the residues
+            // loaded from memory row by row, every wait for them was also a wait for the stores of the row
+            // before: requests complete in order.)
+            uint8_t* const qres = reinterpret_cast<uint8_t*>(stage + lane * SA_LDS_STAGE_DWORDS + 2);
+            {
+                const uint4* src = reinterpret_cast<const uint4*>(P.codes_s + (size_t)sidx * SA_LP);
+                uint2* dst = reinterpret_cast<uint2*>(qres);
+#pragma unroll
+                for (int q4 = 0; q4 < 4; q4++) {
+                    const uint4 v = src[q4];
+                    dst[2 * q4] = make_uint2(v.x, v.y);
+                    dst[2 * q4 + 1] = make_uint2(v.z, v.w);
+                }
+            }
             const int dir_lane = lane * wpr * 4;      // byte offset of this lane inside a direction row
             const int half_off = SA_LP * 256 * wpr;   // byte offset of the high halves' rows
             // direction row of one pair: dword k = columns 16k .. 16k+15, column 16k+i at bits 2(15-i)
@@ -166,33 +164,20 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
                 }
             };
 
-            // Profile rows (as dword offsets) of the two rows to come.  The residues of rows r+2, r+3 are requested
-            // at the top of an iteration and turned into offsets at its end, after the four direction stores, so
-            // that the wait for them stands where those stores may stay in flight.
-            const uint32_t ra = residue(0), rb = residue(1);
-            uint32_t o0, o1;
-            asm volatile("s_waitcnt vmcnt(0)\n\tv_mul_u32_u24 %0, %2, %4\n\tv_mul_u32_u24 %1, %3, %4"
-                         : "=&v"(o0), "=&v"(o1) : "v"(ra), "v"(rb), "s"(SA_PROF_STRIDE) : "memory");
+            // profile rows (as dword offsets) of the two rows to come
+            uint32_t o0 = qres[0] * SA_PROF_STRIDE, o1 = qres[1] * SA_PROF_STRIDE;
             for (int r = 0; r < maxlen; r += 2) {
-                const uint32_t b2 = residue(r + 2), b3 = residue(r + 3);
+                const uint32_t b2 = qres[min(r + 2, SA_LP - 1)], b3 = qres[min(r + 3, SA_LP - 1)];
                 // the row's end tests compare this copy of gend where they stand: hoisted out of the loop they
                 // would each hold a pair of scalar registers, more than there are
                 int gr = gend;
                 asm volatile("" : "+s"(gr));
-                // every lane stores its direction row, also lanes whose sequence 2 has ended (those rows are never
-                // read): every wave then issues exactly four stores per iteration
+                // every lane stores its direction row, also lanes whose sequence 2 has ended (those rows are never read)
                 if (r < lenq) fill_row_pair<NG>(R, Q, gr, SA_NB_UP_B, 0u, prof + o0, e);
                 store_dirs(r, gr);
-                // Memory operations finish in the order they were issued: with at most the two direction stores of
-                // the row above still in flight, the two residues requested before them have arrived.  (The
-                // "memory" clobber keeps those stores on this side of the wait; the requested values have no
-                // other reader than this statement, so nothing copies them before they have arrived.)
-                uint32_t o2, o3;
-                asm volatile("s_waitcnt vmcnt(2)\n\tv_mul_u32_u24 %0, %2, %4\n\tv_mul_u32_u24 %1, %3, %4"
-                             : "=&v"(o2), "=&v"(o3) : "v"(b2), "v"(b3), "s"(SA_PROF_STRIDE) : "memory");
                 if (r + 1 < lenq) fill_row_pair<NG>(Q, R, gr, SA_NB_UP_B, 0u, prof + o1, e);
                 store_dirs(r + 1, gr);
-                o0 = o2; o1 = o3;
+                o0 = b2 * SA_PROF_STRIDE; o1 = b3 * SA_PROF_STRIDE;
             }
             // banks hold 16*D + a tag field per half
             const uint32_t y1q = pick_packed<NC>(Q, lenp1 - 1), y1r = pick_packed<NC>(R, lenp1 - 1);
@@ -202,16 +187,17 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
             __syncthreads();   // direction rows written by this wave are visible to its loads
             SA_PHASE(3);
 
-            // the lane's second sequence, 64 residue codes in 16 registers
+            // the lane's second sequence, 64 residue codes in 16 registers (the staging area takes the records)
             uint32_t bw[16];
             {
-                const uint4* src = reinterpret_cast<const uint4*>(P.codes_s + (size_t)sidx * SA_LP);
+                const uint2* src = reinterpret_cast<const uint2*>(qres);
 #pragma unroll
-                for (int q4 = 0; q4 < 4; q4++) {
-                    const uint4 v = src[q4];
-                    bw[4 * q4 + 0] = v.x; bw[4 * q4 + 1] = v.y; bw[4 * q4 + 2] = v.z; bw[4 * q4 + 3] = v.w;
+                for (int q2 = 0; q2 < 8; q2++) {
+                    const uint2 v = src[q2];
+                    bw[2 * q2] = v.x; bw[2 * q2 + 1] = v.y;
                 }
             }
+            __syncthreads();
 #pragma unroll 1
             for (int half = 0; half < 2; half++) {
                 const bool act = half ? active2 : active;
