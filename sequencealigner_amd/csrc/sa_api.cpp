@@ -116,7 +116,7 @@ struct sa_ctx {
     hipStream_t compute = nullptr, copy = nullptr;
     // tuning
     uint32_t tiles_per_item = 8;
-    uint32_t wg_per_cu = 13;     // 12 are resident (3 waves per SIMD); one more per CU waits and fills the tail
+    uint32_t wg_per_cu = 0;      // workgroups per CU in a launch; 0 = as many as are resident plus one that waits and fills the tail
     bool pairing = true;               // TRIANGULAR peptides: two first sequences per wave where the table allows it
     int64_t sprime_min = 0, sprime_max = 0;   // range of S' = S - 2*gap over the table: decides whether packed cells fit
     uint32_t bucket_width = 1;
@@ -337,17 +337,27 @@ size_t spill_bytes_per_wg(const sa_ctx* c) {
     return (size_t)2 * (c->lslot / 64) * c->lslot * 1024;       // strips x rows x 1 KiB, for each half of the paired kernel
 }
 
+// 4-column register groups of the paired peptide kernel's row: 13 (52 columns) when no sequence is longer
+int pair_groups(const sa_ctx* c) { return c->max_seq <= 52 ? 13 : 16; }
+
 uint32_t grid_for(const sa_ctx* c) {
     if (is_long(c)) {
-        // two waves per SIMD (a third one spills registers inside the row loop: measured 1.8 vs 3.0 TCUPS);
-        // the direction area of a workgroup is large, keep the total under 96 GiB of the 288
+        // 32-bit cells: two waves per SIMD (a third one spills registers inside the row loop: measured 1.8 vs
+        // 3.0 TCUPS).  Packed cells keep one register row and run three, as far as the LDS copies of the two first
+        // sequences allow.  The direction area of a workgroup is large, keep the total under 96 GiB of the 288.
         const uint64_t budget = 96ull << 30;
-        uint64_t g = std::min<uint64_t>((uint64_t)c->ncu * 8, budget / spill_bytes_per_wg(c));
+        uint64_t per_cu = 8;
+        if (uses_pairs(c)) per_cu = std::min<uint64_t>(12, (160u * 1024u) / (SA_LDS_PROF_BYTES + 64 + 2 * c->lslot));
+        uint64_t g = std::min<uint64_t>((uint64_t)c->ncu * per_cu, budget / spill_bytes_per_wg(c));
         return (uint32_t)std::max<uint64_t>(1, g);
     }
-    const uint32_t lds = SA_LDS_FIXED_BYTES + SA_LDS_EMASK_BYTES;
-    uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>(c->wg_per_cu, (160u * 1024u) / lds));
-    return (uint32_t)c->ncu * per_cu;
+    // resident workgroups (= waves) per CU: by registers 4 per SIMD for the 52-column paired kernel, 3 otherwise;
+    // by LDS what fits into 160 KiB
+    const int ng = pair_groups(c);
+    const uint32_t lds = uses_pairs(c) ? SA_PAIR_LDS_BYTES(ng) : SA_LDS_FIXED_BYTES;
+    const uint32_t resident = std::min<uint32_t>(uses_pairs(c) && ng == 13 ? 16 : 12, (160u * 1024u) / lds);
+    const uint32_t per_cu = c->wg_per_cu ? c->wg_per_cu : resident + 1;
+    return (uint32_t)c->ncu * std::max<uint32_t>(1, per_cu);
 }
 
 int ensure_spill(sa_ctx* c, uint32_t grid) {
@@ -403,9 +413,9 @@ int launch_work(sa_ctx* c, Work& w, bool timed) {
     else if (is_long(c))
         sa_launch_long(w.schedule == SA_SCHEDULE_TRIANGULAR ? 0 : 1, &P, grid, SA_LDS_PROF_BYTES + 64 + c->lslot, c->compute);   // + 64: the row reads table entries two groups ahead, up to 16 bytes past the last profile row; + lslot: copy of the shared first sequence
     else if (w.schedule == SA_SCHEDULE_TRIANGULAR && w.paired)
-        sa_launch_peptide_pair(c->max_seq <= 52 ? 13 : 16, &P, grid, SA_LDS_FIXED_BYTES + SA_LDS_EMASK_BYTES, c->compute);
+        sa_launch_peptide_pair(pair_groups(c), &P, grid, SA_PAIR_LDS_BYTES(pair_groups(c)), c->compute);
     else
-        sa_launch_peptide(w.schedule == SA_SCHEDULE_TRIANGULAR ? 0 : 1, c->wg_per_cu > 8 ? 3 : 2, &P, grid,
+        sa_launch_peptide(w.schedule == SA_SCHEDULE_TRIANGULAR ? 0 : 1, (c->wg_per_cu == 0 || c->wg_per_cu > 8) ? 3 : 2, &P, grid,
                           SA_LDS_FIXED_BYTES, c->compute);
     SA_HIP_TRY(hipGetLastError());
     if (timed) SA_HIP_TRY(hipEventRecord(w.t1, c->compute));

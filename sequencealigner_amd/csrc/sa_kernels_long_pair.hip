@@ -106,9 +106,11 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_pair_kernel(const 
                     prof[20 * SA_PROF_STRIDE + lane] = (lane & 1) ? SA_NB_TABLE_B(1) * 0x10001 : SA_NB_TABLE_A(1) * 0x10001;
                     __syncthreads();
                 }
-                uint32_t R[SA_LP], Q[SA_LP];
+                uint32_t R[SA_LP];        // the DP row of the strip, updated in place
 #pragma unroll
-                for (int c = 0; c < SA_LP; c++) { R[c] = Q[c] = (c & 1) ? SA_NB_UP_B : SA_NB_UP_A; }     // border row, base 0
+                for (int c = 0; c < SA_LP; c++) R[c] = (c & 1) ? SA_NB_UP_B : SA_NB_UP_A;                // border row, base 0
+                int capA = 0, capB = 0;   // absolute D at the last column of each half, taken at the lane's last row
+                const int colA = (lenp1 - 1) & 63, colB = (max(lenp2, 1) - 1) & 63;
                 uint32_t e[8];
 #pragma unroll
                 for (int w = 0; w < 8; w++) e[w] = 0;
@@ -149,30 +151,35 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_pair_kernel(const 
                 uint32_t bres = residues4(0);
                 int4 bordA = border4(binA, 0), bordB = border4(binB, 0);
                 int prevA = 0, prevB = 0;                        // border values of the row above the block
-#define SA_LP_ROW(IN, OUT, RR, DA, DB, LA, LB, B)                                                                         \
-    if ((RR) < lenq)                                                                                                       \
-        fill_row_pair<SA_LP / 4, true>(IN, OUT, gend, rel(DA, DB) | SA_NB_UP_B, rel(LA, LB), prof + (B) * SA_PROF_STRIDE, e);    \
-    store_dirs(RR);
+                // Every lane computes and stores every row, also lanes whose sequence 2 has ended (those rows are never
+                // read): with the row under a per-lane condition the compiler keeps a second copy of the register row
+                // for the lanes that skip it.  A lane takes its scores when its last row is done.
+#define SA_LP_ROW(RR, DA, DB, LA, LB, B)                                                                                  \
+    fill_row_pair<SA_LP / 4>(R, gend, rel(DA, DB) | SA_NB_UP_B, rel(LA, LB), prof + (B) * SA_PROF_STRIDE, e);              \
+    store_dirs(RR);                                                                                                        \
+    if ((RR) + 1 == lenq) {                                                                                                \
+        capA = (int)((pick_packed<SA_LP>(R, colA) & 0xffffu) >> SA_NB_SHIFT) + base1;                                      \
+        capB = (int)(pick_packed<SA_LP>(R, colB) >> (16 + SA_NB_SHIFT)) + base2;                                           \
+    }
                 for (int r = 0; r < maxlen; r += 4) {
                     const uint32_t nres = residues4(r + 4);
                     const int4 nbordA = border4(binA, r + 4), nbordB = border4(binB, r + 4);
                     const uint32_t rb0 = bres & 0xff, rb1 = (bres >> 8) & 0xff, rb2 = (bres >> 16) & 0xff, rb3 = bres >> 24;
                     if ((r & 15) == 0 && r > 0 && !first_strip) {
-                        // move the bases up to the border of the row above; the register row (R on a multiple of
-                        // four) follows.  Lanes whose sequence 2 has ended keep what they have.
-                        const int d1 = (r < lenq) ? prevA - base1 : 0, d2 = (r < lenq) ? prevB - base2 : 0;
+                        // move the bases up to the border of the row above; the register row follows
+                        const int d1 = prevA - base1, d2 = prevB - base2;
                         const uint32_t dd = ((uint32_t)d1 << SA_NB_SHIFT) | ((uint32_t)d2 << (16 + SA_NB_SHIFT));
 #pragma unroll
                         for (int c = 0; c < SA_LP; c++) R[c] -= dd;
                         base1 += d1; base2 += d2;
                     }
-                    SA_LP_ROW(R, Q, r, prevA, prevB, bordA.x, bordB.x, rb0)
-                    const uint32_t y0 = Q[SA_LP - 1];
-                    SA_LP_ROW(Q, R, r + 1, bordA.x, bordB.x, bordA.y, bordB.y, rb1)
+                    SA_LP_ROW(r, prevA, prevB, bordA.x, bordB.x, rb0)
+                    const uint32_t y0 = R[SA_LP - 1];
+                    SA_LP_ROW(r + 1, bordA.x, bordB.x, bordA.y, bordB.y, rb1)
                     const uint32_t y1 = R[SA_LP - 1];
-                    SA_LP_ROW(R, Q, r + 2, bordA.y, bordB.y, bordA.z, bordB.z, rb2)
-                    const uint32_t y2 = Q[SA_LP - 1];
-                    SA_LP_ROW(Q, R, r + 3, bordA.z, bordB.z, bordA.w, bordB.w, rb3)
+                    SA_LP_ROW(r + 2, bordA.y, bordB.y, bordA.z, bordB.z, rb2)
+                    const uint32_t y2 = R[SA_LP - 1];
+                    SA_LP_ROW(r + 3, bordA.z, bordB.z, bordA.w, bordB.w, rb3)
                     const uint32_t y3 = R[SA_LP - 1];
                     if (more_strips) {
                         boutA[(size_t)(r >> 2) * 64] = make_int4((int)((y0 & 0xffffu) >> SA_NB_SHIFT) + base1, (int)((y1 & 0xffffu) >> SA_NB_SHIFT) + base1,
@@ -186,14 +193,8 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_pair_kernel(const 
                 }
 #undef SA_LP_ROW
                 // the scores sit in the strips that hold each half's last column
-                if (((lenp1 - 1) >> 6) == s) {
-                    const uint32_t yq = pick_packed<SA_LP>(Q, (lenp1 - 1) & 63), yr = pick_packed<SA_LP>(R, (lenp1 - 1) & 63);
-                    dfin1 = (int)((((lenq & 1) ? yq : yr) & 0xffffu) >> SA_NB_SHIFT) + base1;
-                }
-                if (has2 && ((lenp2 - 1) >> 6) == s) {
-                    const uint32_t yq = pick_packed<SA_LP>(Q, (lenp2 - 1) & 63), yr = pick_packed<SA_LP>(R, (lenp2 - 1) & 63);
-                    dfin2 = (int)(((lenq & 1) ? yq : yr) >> (16 + SA_NB_SHIFT)) + base2;
-                }
+                if (((lenp1 - 1) >> 6) == s) dfin1 = capA;
+                if (has2 && ((lenp2 - 1) >> 6) == s) dfin2 = capB;
                 __syncthreads();   // border column and direction rows are complete before anyone reads them
             }
             SA_PHASE(3);
@@ -296,5 +297,5 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_pair_kernel(const 
 }
 
 extern "C" void sa_launch_long_pair(const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream) {
-    hipLaunchKernelGGL((sa_long_pair_kernel<2>), dim3(grid), dim3(64), lds_bytes, stream, *p);
+    hipLaunchKernelGGL((sa_long_pair_kernel<3>), dim3(grid), dim3(64), lds_bytes, stream, *p);
 }

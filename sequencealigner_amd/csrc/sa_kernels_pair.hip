@@ -32,8 +32,10 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
     int32_t* const prof = reinterpret_cast<int32_t*>(smem);
     // residue codes of the first sequence whose pairs are being traced back: column c at pcol[4 + 2 * c];
     // pcol[192 + c], pcol[256 + c]: those of the item's two first sequences
-    uint8_t* const pcol = smem + SA_LDS_PROF_BYTES;
-    uint32_t* const stage = reinterpret_cast<uint32_t*>(smem + SA_LDS_PROF_BYTES + 2 * SA_LDS_EMASK_BYTES);
+    constexpr int PS = SA_PAIR_PROF_STRIDE(NG);          // dwords between profile rows
+    constexpr int PROF_BYTES = 21 * PS * 4;
+    uint8_t* const pcol = smem + PROF_BYTES;
+    uint32_t* const stage = reinterpret_cast<uint32_t*>(smem + PROF_BYTES + 2 * SA_LDS_EMASK_BYTES);
     const int lane = threadIdx.x;
     // the traceback addresses pcol by its offset inside the workgroup's LDS: the dynamic area starts at 0
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t*)smem != 0u) __builtin_trap();
@@ -69,10 +71,10 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
                 // padding scores 1 instead of 0 (an odd column's table entry must stay positive); padded cells
                 // lie to the right of and below every cell that is read
                 const int s1 = max(P.sprime[a1 * SA_SPRIME_STRIDE + b], 1), s2 = max(P.sprime[a2 * SA_SPRIME_STRIDE + b], 1);
-                prof[b * SA_PROF_STRIDE + lane] = (lane & 1) ? SA_NB_TABLE_B(s1) | (SA_NB_TABLE_B(s2) << 16)
+                if (lane < PS) prof[b * PS + lane] = (lane & 1) ? SA_NB_TABLE_B(s1) | (SA_NB_TABLE_B(s2) << 16)
                                                              : SA_NB_TABLE_A(s1) | (SA_NB_TABLE_A(s2) << 16);
             }
-            prof[20 * SA_PROF_STRIDE + lane] = (lane & 1) ? SA_NB_TABLE_B(1) * 0x10001 : SA_NB_TABLE_A(1) * 0x10001;
+            if (lane < PS) prof[20 * PS + lane] = (lane & 1) ? SA_NB_TABLE_B(1) * 0x10001 : SA_NB_TABLE_A(1) * 0x10001;
             pcol[192 + lane] = (uint8_t)a1;      // kept for the tracebacks: see the loop over the two halves
             pcol[256 + lane] = (uint8_t)a2;
             __syncthreads();
@@ -108,9 +110,9 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
             SA_PHASE(2);
 
             // -------------------------------------------------------------- fill
-            uint32_t R[NC], Q[NC];
+            uint32_t R[NC];      // the DP row, updated in place
 #pragma unroll
-            for (int c = 0; c < NC; c++) { R[c] = Q[c] = (c & 1) ? SA_NB_UP_B : SA_NB_UP_A; }
+            for (int c = 0; c < NC; c++) R[c] = (c & 1) ? SA_NB_UP_B : SA_NB_UP_A;
             uint32_t e[NACC];
 #pragma unroll
             for (int w = 0; w < NACC; w++) e[w] = 0;
@@ -164,26 +166,30 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
                 }
             };
 
-            // profile rows (as dword offsets) of the two rows to come
-            uint32_t o0 = qres[0] * SA_PROF_STRIDE, o1 = qres[1] * SA_PROF_STRIDE;
-            for (int r = 0; r < maxlen; r += 2) {
-                const uint32_t b2 = qres[min(r + 2, SA_LP - 1)], b3 = qres[min(r + 3, SA_LP - 1)];
+            // profile row (as a dword offset) of the row to come
+            uint32_t o0 = qres[0] * PS;
+            uint32_t dfin1 = 0, dfin2 = 0;       // bank values of the last cells of the two matrices
+            for (int r = 0; r < maxlen; r++) {
+                const uint32_t b1 = qres[min(r + 1, SA_LP - 1)];
                 // the row's end tests compare this copy of gend where they stand: hoisted out of the loop they
                 // would each hold a pair of scalar registers, more than there are
                 int gr = gend;
                 asm volatile("" : "+s"(gr));
-                // every lane stores its direction row, also lanes whose sequence 2 has ended (those rows are never read)
-                if (r < lenq) fill_row_pair<NG>(R, Q, gr, SA_NB_UP_B, 0u, prof + o0, e);
+                // Every lane computes and stores every row, also lanes whose sequence 2 has ended (padding
+                // residues; those rows are never read): with the row under a per-lane condition the compiler
+                // keeps a second copy of the register row for the lanes that skip it.  A lane takes its
+                // scores when its last row is done.
+                fill_row_pair<NG>(R, gr, SA_NB_UP_B, 0u, prof + o0, e);
                 store_dirs(r, gr);
-                if (r + 1 < lenq) fill_row_pair<NG>(Q, R, gr, SA_NB_UP_B, 0u, prof + o1, e);
-                store_dirs(r + 1, gr);
-                o0 = b2 * SA_PROF_STRIDE; o1 = b3 * SA_PROF_STRIDE;
+                if (r + 1 == lenq) {
+                    dfin1 = pick_packed<NC>(R, lenp1 - 1);
+                    dfin2 = pick_packed<NC>(R, max(lenp2, 1) - 1);
+                }
+                o0 = b1 * PS;
             }
-            // banks hold 16*D + a tag field per half
-            const uint32_t y1q = pick_packed<NC>(Q, lenp1 - 1), y1r = pick_packed<NC>(R, lenp1 - 1);
-            const uint32_t y2q = pick_packed<NC>(Q, max(lenp2, 1) - 1), y2r = pick_packed<NC>(R, max(lenp2, 1) - 1);
-            const int d1 = (int)((((lenq & 1) ? y1q : y1r) & 0xffffu) >> SA_NB_SHIFT);
-            const int d2 = (int)(((lenq & 1) ? y2q : y2r) >> (16 + SA_NB_SHIFT));
+            // the bank holds 16*D + a tag field per half
+            const int d1 = (int)((dfin1 & 0xffffu) >> SA_NB_SHIFT);
+            const int d2 = (int)(dfin2 >> (16 + SA_NB_SHIFT));
             __syncthreads();   // direction rows written by this wave are visible to its loads
             SA_PHASE(3);
 
@@ -210,7 +216,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
                 const int base = half ? half_off : 0;
                 int matches = 0, gaps = 0;
 #define SA_TRACEBACK(WW)                                                                                   \
-    traceback_pk<WW, SA_LDS_PROF_BYTES + 4>(lane, mlen, lq, lenp, spill_words, base, bw,                    \
+    traceback_pk<WW, PROF_BYTES + 4>(lane, mlen, lq, lenp, spill_words, base, bw,                    \
                                             stage + lane * SA_LDS_STAGE_DWORDS, matches, gaps)
                 if (wpr == 4) SA_TRACEBACK(4);
                 else if (wpr == 3) SA_TRACEBACK(3);
@@ -253,7 +259,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
 // row loop: 180 ms against 162 ms with two waves per SIMD on 40 000 sequences of 6..64 residues).
 extern "C" void sa_launch_peptide_pair(int ng, const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream) {
     if (ng <= 13)
-        hipLaunchKernelGGL((sa_peptide_pair_kernel<13, 3>), dim3(grid), dim3(64), lds_bytes, stream, *p);
+        hipLaunchKernelGGL((sa_peptide_pair_kernel<13, 4>), dim3(grid), dim3(64), lds_bytes, stream, *p);
     else
-        hipLaunchKernelGGL((sa_peptide_pair_kernel<16, 2>), dim3(grid), dim3(64), lds_bytes, stream, *p);
+        hipLaunchKernelGGL((sa_peptide_pair_kernel<16, 3>), dim3(grid), dim3(64), lds_bytes, stream, *p);
 }

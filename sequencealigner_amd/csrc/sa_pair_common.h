@@ -35,84 +35,76 @@
 #define SA_NB_TABLE_B(sprime) (16 * (sprime) - 5)
 #define SA_NB_SHIFT 4
 
-// Columns C (even) and C + 1 of both pairs as one block of instructions.  The tags of the two columns go to
-// bits 4(3-i) .. 4(3-i)+3 of each half of the direction word, i = (C mod 8) / 2: a word that takes fewer than
-// eight columns is filled from the top.  The first deposit of a word (a packed 16-bit shift, which also
-// drops the D bits that came along from the odd column) overwrites the word.
+// Columns C (even) and C + 1 of both pairs as one block of instructions, in place: B[C] and B[C + 1] hold the bank
+// values of the row above when the block starts and those of this row when it ends (one register row, not two:
+// each is read as the UP operand before it is written, and the diagonal operands -- MA for the even column, MB
+// for the odd one, table entries already added -- were taken from the row above before the block that
+// overwrites their source).  MB leaves as the raw result of the odd column, the LEFT operand of the next block.
+// The tags of the two columns go to bits 4(3-i) .. 4(3-i)+3 of each half of the direction word,
+// i = (C mod 8) / 2: a word that takes fewer than eight columns is filled from the top.  The first deposit of a
+// word (a packed 16-bit shift, which also drops the D bits that came along from the odd column) overwrites it.
 #define SA_NB_HEAD                                                  \
-    "v_pk_maximum3_f16 %[ma], %[ma], %[upa], %[zl]\n\t"             \
+    "v_pk_maximum3_f16 %[ma], %[ma], %[ba], %[zl]\n\t"              \
     "v_and_b32 %[la], 0xfff0fff0, %[ma]\n\t"                        \
-    "v_or_b32 %[outa], 0x80008, %[la]\n\t"                          \
-    "v_pk_maximum3_f16 %[mb], %[mb], %[upb], %[la]\n\t"             \
+    "v_or_b32 %[ba], 0x80008, %[la]\n\t"                            \
+    "v_pk_maximum3_f16 %[mb], %[mb], %[bb], %[la]\n\t"              \
     "v_bfi_b32 %[t], %[fielda], %[ma], %[mb]\n\t"
-#define SA_NB_TAIL "v_and_or_b32 %[outb], %[mb], %[clean], %[two]"
-#define SA_NB_OPERANDS(ACC_CONSTRAINT, IN, OUT, C, ACC)                                                                      \
-    : [ma] "+v"(ma_), [mb] "+v"(mb_), [la] "=&v"(la_), [t] "=&v"(t_), [outa] "=&v"(OUT[C]),                  \
-      [outb] "=&v"(OUT[(C) + 1]), [acc] ACC_CONSTRAINT(ACC)                                                   \
-    : [upa] "v"(IN[C]), [upb] "v"(IN[(C) + 1]), [zl] "v"(zl), [fielda] "s"(0x000c000cu), [clean] "s"(0xfff0fff0u), \
-      [two] "v"(upb), [low] "s"(0x000f000fu)
-#define SA_CELL_NB(IN, OUT, C, TA, TB, ACC)                                                     \
+#define SA_NB_TAIL "v_and_or_b32 %[bb], %[mb], %[clean], %[two]"
+#define SA_NB_OPERANDS(ACC_CONSTRAINT, B, C, MA, MB, ACC)                                                    \
+    : [ma] "+v"(MA), [mb] "+v"(MB), [ba] "+v"(B[C]), [bb] "+v"(B[(C) + 1]), [la] "=&v"(la_), [t] "=&v"(t_),    \
+      [acc] ACC_CONSTRAINT(ACC)                                                                              \
+    : [zl] "v"(zl), [fielda] "s"(0x000c000cu), [clean] "s"(0xfff0fff0u), [two] "v"(upb), [low] "s"(0x000f000fu)
+#define SA_CELL_NB(B, C, MA, MB, ACC)                                                           \
     {                                                                                           \
-        uint32_t ma_ = (((C) == 0) ? diag0 : IN[((C) == 0) ? 0 : (C) - 1]) + (uint32_t)(TA);    \
-        uint32_t mb_ = IN[C] + (uint32_t)(TB);                                                  \
         uint32_t la_, t_;                                                                       \
         if (((C) & 7) == 0) {                                                                   \
-            asm volatile(SA_NB_HEAD "v_pk_lshlrev_b16 %[acc], 12, %[t] op_sel_hi:[0,1]\n\t" SA_NB_TAIL SA_NB_OPERANDS("=&v", IN, OUT, C, ACC)); \
+            asm volatile(SA_NB_HEAD "v_pk_lshlrev_b16 %[acc], 12, %[t] op_sel_hi:[0,1]\n\t" SA_NB_TAIL SA_NB_OPERANDS("=&v", B, C, MA, MB, ACC)); \
         } else if (((C) & 7) == 2) {                                                            \
-            asm volatile(SA_NB_HEAD "v_and_b32 %[t], %[low], %[t]\n\tv_lshl_or_b32 %[acc], %[t], 8, %[acc]\n\t" SA_NB_TAIL SA_NB_OPERANDS("+v", IN, OUT, C, ACC)); \
+            asm volatile(SA_NB_HEAD "v_and_b32 %[t], %[low], %[t]\n\tv_lshl_or_b32 %[acc], %[t], 8, %[acc]\n\t" SA_NB_TAIL SA_NB_OPERANDS("+v", B, C, MA, MB, ACC)); \
         } else if (((C) & 7) == 4) {                                                            \
-            asm volatile(SA_NB_HEAD "v_and_b32 %[t], %[low], %[t]\n\tv_lshl_or_b32 %[acc], %[t], 4, %[acc]\n\t" SA_NB_TAIL SA_NB_OPERANDS("+v", IN, OUT, C, ACC)); \
+            asm volatile(SA_NB_HEAD "v_and_b32 %[t], %[low], %[t]\n\tv_lshl_or_b32 %[acc], %[t], 4, %[acc]\n\t" SA_NB_TAIL SA_NB_OPERANDS("+v", B, C, MA, MB, ACC)); \
         } else {                                                                                \
-            asm volatile(SA_NB_HEAD "v_and_or_b32 %[acc], %[t], %[low], %[acc]\n\t" SA_NB_TAIL SA_NB_OPERANDS("+v", IN, OUT, C, ACC)); \
+            asm volatile(SA_NB_HEAD "v_and_or_b32 %[acc], %[t], %[low], %[acc]\n\t" SA_NB_TAIL SA_NB_OPERANDS("+v", B, C, MA, MB, ACC)); \
         }                                                                                       \
-        zl = mb_;                                                                               \
+        zl = MB;                                                                                \
     }
 
-// Four columns.  Rows end early: gend = ceil(longer first sequence / 4).
-// AHEAD = false: every group reads its own table entries and waits for them (a request the source places a
-// group ahead is moved by the compiler behind the row's end test, to where its value is used).  With three waves
-// per SIMD the other waves cover that wait, and hand-placed requests gained nothing.
-// AHEAD = true: the entries of group G + 1 are requested, as an instruction of its own, before the cells of
-// group G, and waited for by count: requests to the LDS complete in the order they were issued, so "at most
-// one outstanding" means that all but the newest have arrived.  The request for the group behind the row's end
-// stays inside the profile row and is never used.  For kernels that run two waves per SIMD.
+// Four columns.  Rows end early: gend = ceil(longer first sequence / 4).  The table entries of group G + 1 are
+// read while group G is worked on (their first one is needed there, for the diagonal operand of the next even
+// column, so the read stays where it is).  The read for the group behind the row's end stays inside the profile
+// row and is not used.
 typedef int sa_i32x4 __attribute__((ext_vector_type(4)));
-#define SA_LDS_REQUEST(DST, ADDR, BYTES) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(BYTES))
-#define SA_GROUP_PK(G, CUR, NXT)                                                   \
-    if (AHEAD) {                                                                   \
-        if ((G) + 1 < NG) {                                                        \
-            SA_LDS_REQUEST(NXT, row_addr, 16 * ((G) + 1));                         \
-            asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(CUR));                      \
-        } else {                                                                   \
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(CUR));                      \
-        }                                                                          \
-    } else {                                                                       \
-        CUR = *reinterpret_cast<const sa_i32x4*>(row_base + 4 * (G));              \
-    }                                                                              \
-    SA_CELL_NB(IN, OUT, 4 * (G) + 0, CUR.x, CUR.y, e[(G) >> 1])                    \
-    SA_CELL_NB(IN, OUT, 4 * (G) + 2, CUR.z, CUR.w, e[(G) >> 1])                    \
-    if (NG == (G) + 1 || gend == (G) + 1) return;
+#define SA_GROUP_PK(G)                                                                          \
+    {                                                                                           \
+        sa_i32x4 nsc_ = sc_;                                                                    \
+        if ((G) + 1 < NG) nsc_ = *reinterpret_cast<const sa_i32x4*>(row_base + 4 * ((G) + 1));  \
+        uint32_t mb0_ = B[4 * (G)] + (uint32_t)sc_.y;                                           \
+        uint32_t ma1_ = B[4 * (G) + 1] + (uint32_t)sc_.z;                                       \
+        SA_CELL_NB(B, 4 * (G), ma_, mb0_, e[(G) >> 1])                                          \
+        uint32_t mb1_ = B[4 * (G) + 2] + (uint32_t)sc_.w;                                       \
+        const uint32_t man_ = B[4 * (G) + 3] + (uint32_t)nsc_.x;                                \
+        SA_CELL_NB(B, 4 * (G) + 2, ma1_, mb1_, e[(G) >> 1])                                     \
+        if (NG == (G) + 1 || gend == (G) + 1) return;                                           \
+        sc_ = nsc_; ma_ = man_;                                                                 \
+    }
 
-// One packed DP row of 16*D cells: IN = previous row, OUT = this row, columns 0 .. 4*gend-1.  diag0 = border
-// value of the previous row in odd-column bank form (SA_NB_UP_B on the matrix border), left0 = this row's
-// border value with the tags cleared (0 on the matrix border).
+// One packed DP row of 16*D cells, in place: B = the row above on entry, this row on return, columns
+// 0 .. 4*gend-1.  diag0 = border value of the row above in odd-column bank form (SA_NB_UP_B on the matrix
+// border), left0 = this row's border value with the tags cleared (0 on the matrix border).
 // e[w] receives the tags of columns 8w .. 8w+7 of both pairs: column 8w+i at bits 2(7-i) of each 16-bit
 // half, also when the row ends after four columns of the word.
-template <int NG, bool AHEAD = false>
-__device__ __forceinline__ void fill_row_pair(const uint32_t (&IN)[4 * NG], uint32_t (&OUT)[4 * NG], const int gend,
+template <int NG>
+__device__ __forceinline__ void fill_row_pair(uint32_t (&B)[4 * NG], const int gend,
                                               const uint32_t diag0, const uint32_t left0,
                                               const int32_t* __restrict__ row_base, uint32_t (&e)[(NG + 1) / 2]) {
     uint32_t zl = left0;
     uint32_t upb = SA_NB_UP_B;
     asm volatile("" : "+v"(upb));          // one register for the whole row, not a copy per use
-    sa_i32x4 scE, scO;
-    const uint32_t row_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const int32_t*)row_base;
-    if (AHEAD) SA_LDS_REQUEST(scE, row_addr, 0);
-    SA_GROUP_PK(0, scE, scO) SA_GROUP_PK(1, scO, scE) SA_GROUP_PK(2, scE, scO) SA_GROUP_PK(3, scO, scE)
-    SA_GROUP_PK(4, scE, scO) SA_GROUP_PK(5, scO, scE) SA_GROUP_PK(6, scE, scO) SA_GROUP_PK(7, scO, scE)
-    SA_GROUP_PK(8, scE, scO) SA_GROUP_PK(9, scO, scE) SA_GROUP_PK(10, scE, scO) SA_GROUP_PK(11, scO, scE)
-    SA_GROUP_PK(12, scE, scO)
-    if constexpr (NG > 13) { SA_GROUP_PK(13, scO, scE) SA_GROUP_PK(14, scE, scO) SA_GROUP_PK(15, scO, scE) }
+    sa_i32x4 sc_ = *reinterpret_cast<const sa_i32x4*>(row_base);
+    uint32_t ma_ = diag0 + (uint32_t)sc_.x;
+    SA_GROUP_PK(0) SA_GROUP_PK(1) SA_GROUP_PK(2) SA_GROUP_PK(3) SA_GROUP_PK(4) SA_GROUP_PK(5) SA_GROUP_PK(6)
+    SA_GROUP_PK(7) SA_GROUP_PK(8) SA_GROUP_PK(9) SA_GROUP_PK(10) SA_GROUP_PK(11) SA_GROUP_PK(12)
+    if constexpr (NG > 13) { SA_GROUP_PK(13) SA_GROUP_PK(14) SA_GROUP_PK(15) }
 }
 
 
