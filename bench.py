@@ -178,7 +178,7 @@ def main():
         if hi > 64:
             kernel = "sa_long_pair_kernel<3>"
         else:
-            kernel = "sa_peptide_pair_kernel<13, 4>" if hi <= 52 else "sa_peptide_pair_kernel<16, 3>"
+            kernel = "sa_peptide_pair_kernel<13, 4>" if hi <= 52 else "sa_peptide_pair_kernel<16, 4>"
         achieved = my_cells * OPS_PER_CELL / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         traffic = measured_traffic(kernel, args.workload) if world == 1 and k_ms > 0 else None
         out = {

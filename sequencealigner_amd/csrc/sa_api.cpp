@@ -351,11 +351,11 @@ uint32_t grid_for(const sa_ctx* c) {
         uint64_t g = std::min<uint64_t>((uint64_t)c->ncu * per_cu, budget / spill_bytes_per_wg(c));
         return (uint32_t)std::max<uint64_t>(1, g);
     }
-    // resident workgroups (= waves) per CU: by registers 4 per SIMD for the 52-column paired kernel, 3 otherwise;
-    // by LDS what fits into 160 KiB
+    // resident workgroups (= waves) per CU: by registers 4 per SIMD for the paired kernel, 3 otherwise; by LDS what
+    // fits into 160 KiB
     const int ng = pair_groups(c);
     const uint32_t lds = uses_pairs(c) ? SA_PAIR_LDS_BYTES(ng) : SA_LDS_FIXED_BYTES;
-    const uint32_t resident = std::min<uint32_t>(uses_pairs(c) && ng == 13 ? 16 : 12, (160u * 1024u) / lds);
+    const uint32_t resident = std::min<uint32_t>(uses_pairs(c) ? 16 : 12, (160u * 1024u) / lds);
     const uint32_t per_cu = c->wg_per_cu ? c->wg_per_cu : resident + 1;
     return (uint32_t)c->ncu * std::max<uint32_t>(1, per_cu);
 }

@@ -1,22 +1,18 @@
 // sa_kernels_pair.hip -- TRIANGULAR peptides, two first sequences per wave.
 //
-// Same recurrence and the same tagged cells as sa_kernels.hip, but every VGPR of
-// the DP row holds two cells: the low 16 bits belong to the pair (p1, q), the high
-// 16 bits to (p2, q), where q is the lane's second sequence and p1 < p2 are two
-// first sequences of the same length bucket.  A lane's row residue b is the same
-// for both matrices, so one LDS lookup prof[b][c] = T(p1)[b][c] | T(p2)[b][c] << 16
-// feeds both; the add is a plain 32-bit add (no carry can cross: every half stays
-// below 2^15), the two max are v_pk_max_i16, and the tag/clean/bank steps are
-// 32-bit bit operations on both halves at once.  Per two cells: add, 2 x pk_max,
-// and (tags), shift-or (direction word), and (left operand), or (bank value) --
-// 3.5 instructions per cell against 5 for the unpaired kernel.
+// Same recurrence as sa_kernels.hip, but every VGPR of the DP row holds two cells: the low
+// 16 bits belong to the pair (p1, q), the high 16 bits to (p2, q), where q is the lane's
+// second sequence and p1 < p2 are two first sequences of the same length bucket.  A lane's
+// row residue b is the same for both matrices, so one LDS lookup
+// prof[b][c] = T(p1)[b][c] | T(p2)[b][c] << 16 feeds both.  Cell format, instruction
+// blocks and the in-place register row: sa_pair_common.h.  About 2.4 instructions per cell
+// against 5 for the unpaired kernel.
 //
-// Tags: 0 LEFT, 2 UP, 3 DIAG (bank values 4*D + 2, table entries 4*S' + 1), so that
-// with the newest column in the low bits of a direction word a count-trailing-zeros
-// finds a run of LEFT moves (sa_traceback.h, REV = 1).
+// Tags: 0 LEFT, 2 UP, 3 DIAG, so that with the newest column in the low bits of a direction
+// word a count-trailing-zeros finds a run of LEFT moves (sa_traceback.h, traceback_pk).
 //
-// The host uses this kernel only when every half provably stays in range:
-// 0 <= S' <= 120 for the whole table (BLOSUM50 with gap -4: 3 .. 23).
+// The host uses this kernel only when every half provably stays in range: S' >= 1 and
+// longest sequence * max S' <= 1983 (BLOSUM50 with gap -4: S' = 3 .. 23).
 //
 // The lanes of a task are 64 consecutive entries of p1's valid list; the pair
 // (p2, q) exists only where q's file index is above p2 (all but the few sequences
@@ -254,12 +250,11 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
 #undef SA_PHASE
 }
 
-// ng: 4-column groups the register row holds (13: sequences up to 52 residues, 16: up to 64).  The 52-column
-// row fits three waves per SIMD without scratch; the 64-column row does not (68 bytes of scratch inside the
-// row loop: 180 ms against 162 ms with two waves per SIMD on 40 000 sequences of 6..64 residues).
+// ng: 4-column groups the register row holds (13: sequences up to 52 residues, 16: up to 64).  Both fit 128
+// registers, four waves per SIMD; the shorter row leaves room in the LDS for one more workgroup per CU.
 extern "C" void sa_launch_peptide_pair(int ng, const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream) {
     if (ng <= 13)
         hipLaunchKernelGGL((sa_peptide_pair_kernel<13, 4>), dim3(grid), dim3(64), lds_bytes, stream, *p);
     else
-        hipLaunchKernelGGL((sa_peptide_pair_kernel<16, 3>), dim3(grid), dim3(64), lds_bytes, stream, *p);
+        hipLaunchKernelGGL((sa_peptide_pair_kernel<16, 4>), dim3(grid), dim3(64), lds_bytes, stream, *p);
 }
