@@ -67,10 +67,10 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
                 // padding scores 1 instead of 0 (an odd column's table entry must stay positive); padded cells
                 // lie to the right of and below every cell that is read
                 const int s1 = max(P.sprime[a1 * SA_SPRIME_STRIDE + b], 1), s2 = max(P.sprime[a2 * SA_SPRIME_STRIDE + b], 1);
-                if (lane < PS) prof[b * PS + lane] = (lane & 1) ? SA_NB_TABLE_B(s1) | (SA_NB_TABLE_B(s2) << 16)
+                if (lane < PS) prof[b * PS + SA_NB_PROF_INDEX(lane, PS)] = (lane & 1) ? SA_NB_TABLE_B(s1) | (SA_NB_TABLE_B(s2) << 16)
                                                              : SA_NB_TABLE_A(s1) | (SA_NB_TABLE_A(s2) << 16);
             }
-            if (lane < PS) prof[20 * PS + lane] = (lane & 1) ? SA_NB_TABLE_B(1) * 0x10001 : SA_NB_TABLE_A(1) * 0x10001;
+            if (lane < PS) prof[20 * PS + SA_NB_PROF_INDEX(lane, PS)] = (lane & 1) ? SA_NB_TABLE_B(1) * 0x10001 : SA_NB_TABLE_A(1) * 0x10001;
             pcol[192 + lane] = (uint8_t)a1;      // kept for the tracebacks: see the loop over the two halves
             pcol[256 + lane] = (uint8_t)a2;
             __syncthreads();
@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
                 // residues; those rows are never read): with the row under a per-lane condition the compiler
                 // keeps a second copy of the register row for the lanes that skip it.  A lane takes its
                 // scores when its last row is done.
-                fill_row_pair<NG>(R, gr, SA_NB_UP_B, 0u, prof + o0, e);
+                fill_row_pair<NG, PS>(R, gr, SA_NB_UP_B, 0u, prof + o0, e);
                 store_dirs(r, gr);
                 if (r + 1 == lenq) {
                     dfin1 = pick_packed<NC>(R, lenp1 - 1);

@@ -69,43 +69,49 @@
         zl = MB;                                                                                \
     }
 
-// Four columns.  Rows end early: gend = ceil(longer first sequence / 4).  The table entries of group G + 1 are
-// read while group G is worked on (their first one is needed there, for the diagonal operand of the next even
-// column, so the read stays where it is).  The read for the group behind the row's end stays inside the profile
-// row and is not used.
+// Four columns.  Rows end early: gend = ceil(longer first sequence / 4).
+// Profile rows are stored one column to the left: dword k of a row holds the table entry of column k + 1, the
+// entry of column 0 stands in the row's last dword (PS - 1).  The four entries group G reads are then those of
+// columns 4G+1 .. 4G+4, all it needs: the diagonal operands of its own columns 4G+1, 4G+2, 4G+3 and of the next
+// group's first column, which must be taken from the row above before this group overwrites it.  That last add
+// is written as an instruction so that it stays here: left to the compiler it moves into the next group (the
+// only place its result is used) behind a copy of the register it reads.
 typedef int sa_i32x4 __attribute__((ext_vector_type(4)));
 #define SA_GROUP_PK(G)                                                                          \
     {                                                                                           \
-        sa_i32x4 nsc_ = sc_;                                                                    \
-        if ((G) + 1 < NG) nsc_ = *reinterpret_cast<const sa_i32x4*>(row_base + 4 * ((G) + 1));  \
-        uint32_t mb0_ = B[4 * (G)] + (uint32_t)sc_.y;                                           \
-        uint32_t ma1_ = B[4 * (G) + 1] + (uint32_t)sc_.z;                                       \
+        const sa_i32x4 sc_ = *reinterpret_cast<const sa_i32x4*>(row_base + 4 * (G));            \
+        uint32_t mb0_ = B[4 * (G)] + (uint32_t)sc_.x;                                           \
+        uint32_t ma1_ = B[4 * (G) + 1] + (uint32_t)sc_.y;                                       \
         SA_CELL_NB(B, 4 * (G), ma_, mb0_, e[(G) >> 1])                                          \
-        uint32_t mb1_ = B[4 * (G) + 2] + (uint32_t)sc_.w;                                       \
-        const uint32_t man_ = B[4 * (G) + 3] + (uint32_t)nsc_.x;                                \
+        uint32_t mb1_ = B[4 * (G) + 2] + (uint32_t)sc_.z;                                       \
+        uint32_t man_ = 0;                                                                      \
+        if ((G) + 1 < NG) asm volatile("v_add_u32 %0, %1, %2" : "=v"(man_) : "v"(B[4 * (G) + 3]), "v"(sc_.w)); \
         SA_CELL_NB(B, 4 * (G) + 2, ma1_, mb1_, e[(G) >> 1])                                     \
         if (NG == (G) + 1 || gend == (G) + 1) return;                                           \
-        sc_ = nsc_; ma_ = man_;                                                                 \
+        ma_ = man_;                                                                             \
     }
 
 // One packed DP row of 16*D cells, in place: B = the row above on entry, this row on return, columns
 // 0 .. 4*gend-1.  diag0 = border value of the row above in odd-column bank form (SA_NB_UP_B on the matrix
-// border), left0 = this row's border value with the tags cleared (0 on the matrix border).
+// border), left0 = this row's border value with the tags cleared (0 on the matrix border).  row_base: the
+// lane's profile row, PS dwords long, laid out as described above.
 // e[w] receives the tags of columns 8w .. 8w+7 of both pairs: column 8w+i at bits 2(7-i) of each 16-bit
 // half, also when the row ends after four columns of the word.
-template <int NG>
+template <int NG, int PS>
 __device__ __forceinline__ void fill_row_pair(uint32_t (&B)[4 * NG], const int gend,
                                               const uint32_t diag0, const uint32_t left0,
                                               const int32_t* __restrict__ row_base, uint32_t (&e)[(NG + 1) / 2]) {
     uint32_t zl = left0;
     uint32_t upb = SA_NB_UP_B;
     asm volatile("" : "+v"(upb));          // one register for the whole row, not a copy per use
-    sa_i32x4 sc_ = *reinterpret_cast<const sa_i32x4*>(row_base);
-    uint32_t ma_ = diag0 + (uint32_t)sc_.x;
+    uint32_t ma_ = diag0 + (uint32_t)row_base[PS - 1];
     SA_GROUP_PK(0) SA_GROUP_PK(1) SA_GROUP_PK(2) SA_GROUP_PK(3) SA_GROUP_PK(4) SA_GROUP_PK(5) SA_GROUP_PK(6)
     SA_GROUP_PK(7) SA_GROUP_PK(8) SA_GROUP_PK(9) SA_GROUP_PK(10) SA_GROUP_PK(11) SA_GROUP_PK(12)
     if constexpr (NG > 13) { SA_GROUP_PK(13) SA_GROUP_PK(14) SA_GROUP_PK(15) }
 }
+
+// dword of a profile row that takes the table entry of column c (see above)
+#define SA_NB_PROF_INDEX(c, PS) ((c) == 0 ? (PS) - 1 : (c) - 1)
 
 
 // value of register column `col` (wave-uniform) of a packed row bank
