@@ -138,11 +138,12 @@ int sa_prepare_resident(sa_ctx* ctx, int schedule, uint64_t row_begin, uint64_t 
 int sa_run_resident(sa_ctx* ctx, float* kernel_ms);
 int sa_fetch_resident(sa_ctx* ctx, uint64_t first, uint64_t n, uint8_t* dst);
 /* tuning knobs of the peptide kernel: 64-pair tiles per work item, workgroups (waves)
- * per CU; 0 keeps the current value */
+ * per CU in a launch; 0 keeps the current value.  Until wg_per_cu is set the library launches
+ * as many workgroups per CU as registers and LDS let reside there, plus one. */
 int sa_set_tuning(sa_ctx* ctx, uint32_t tiles_per_item, uint32_t wg_per_cu);
 /* TRIANGULAR work normally runs on kernels that handle two first sequences per wave in packed
- * 16-bit cells; they are used only when the substitution table allows it (0 <= S - 2*gap <= 120
- * everywhere when no sequence exceeds 64 residues, <= 48 otherwise).  enable = 0 forces one first
+ * 16-bit cells; they are used only when the substitution table allows it (S - 2*gap >= 1 everywhere
+ * and longest sequence * max(S - 2*gap) <= 1983 when no sequence exceeds 64 residues; 1 .. 24 otherwise).  enable = 0 forces one first
  * sequence per wave, 32-bit cells (same results; for comparisons and tests).  Default: enabled. */
 int sa_set_pairing(sa_ctx* ctx, int enable);
 
