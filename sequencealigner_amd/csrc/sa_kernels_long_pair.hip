@@ -202,8 +202,8 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_pair_kernel(const 
             // --------------------------------------------------------- traceback, one half after the other
             // One row per step, bottom row first, eight rows per 16-byte piece of the record.  The tags of a row
             // are requested eight rows ahead for the strip the walk is in at that moment (a wrong guess is loaded
-            // again when it is used, an ordinary load); the row residues come as two dwords a piece ahead; the
-            // first sequence is read from its LDS copy.  Tag layout: column c of a strip at bits 2(15 - c%16) of dword c/16.
+            // again when it is used); the row residues come as two dwords a piece ahead; the first sequence is
+            // read from its LDS copy.  Tag layout: column c of a strip at bits 2(15 - c%16) of dword c/16.
 #pragma unroll 1
             for (int half = 0; half < 2; half++) {
                 const bool act = half ? active2 : active;
@@ -215,57 +215,34 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_pair_kernel(const 
                 const uint8_t* ps = pseq + (half ? P.lslot : 0);
                 uint8_t* rec = (half ? out_row2 : out_row1) + (size_t)(fiq - (half ? p2 : p1) - 1) * P.stride;
                 int j = lenp, matches = 0, gaps = 0;
-                auto tag_ptr = [&](int sj, int r) -> const uint32_t* {
-                    return hd + (((size_t)sj * rows_cap + min(r, last_row)) * 64 + lane) * 4;
+                auto load_tags = [&](int sj, int r) -> uint4 {
+                    return *reinterpret_cast<const uint4*>(hd + (((size_t)sj * rows_cap + min(r, last_row)) * 64 + lane) * 4);
                 };
-                // The requests that run ahead are written as instructions with hand-counted waits.  Memory requests
-                // complete in the order they were issued; between the request for a row (or for a piece's residues)
-                // and its use one piece later there are at least eight younger requests, so "at most 8 outstanding"
-                // means it has arrived.  Left to the compiler every use waits for everything in flight, the request
-                // issued one row earlier included, and the walk pays a memory round trip per row.  Each register
-                // set has one request site, and its one reader is the statement that waits: a value still on its
-                // way must not be copied by the compiler.  The loop starts one piece above the first: there it only
-                // requests.
-                sa_u32x4 ring[8];
-                sa_u32x2 resq;
-#pragma unroll
-                for (int k = 0; k < 8; k++) asm volatile("" : "=v"(ring[k]));
-                asm volatile("" : "=v"(resq));
+                uint4 ring[8];
                 int ring_s[8];
-#pragma unroll
-                for (int k = 0; k < 8; k++) ring_s[k] = -1;
                 const int ch0 = (mlen - 1) >> 3;
-                for (int ch = ch0 + 1; ch >= 0; --ch) {
+                {
+                    const int s0 = (lenp - 1) >> 6;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) { ring[k] = load_tags(s0, 8 * ch0 + k); ring_s[k] = s0; }
+                }
+                uint2 resq = *reinterpret_cast<const uint2*>(bslot + min(8 * ch0, last_row - 7));
+                for (int ch = ch0; ch >= 0; --ch) {
                     uint32_t w[4] = {0, 0, 0, 0};
-                    // In the last piece nothing more is requested and the count no longer holds: everything is taken in.
-                    sa_u32x2 res;
-                    if (ch == 0) asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %1, %3"
-                                              : "=&v"(res.x), "=&v"(res.y) : "v"(resq.x), "v"(resq.y) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(8)\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %1, %3"
-                                      : "=&v"(res.x), "=&v"(res.y) : "v"(resq.x), "v"(resq.y) : "memory");
-                    if (ch > 0) {
-                        const uint8_t* rp = bslot + min(8 * (ch - 1), last_row - 7);
-                        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(resq) : "v"(rp) : "memory");
-                    }
+                    const uint2 res = resq;
+                    if (ch > 0) resq = *reinterpret_cast<const uint2*>(bslot + 8 * (ch - 1));
 #pragma unroll
                     for (int k = 7; k >= 0; k--) {
                         const int r = 8 * ch + k;
-                        // the wait and the copy out of the request's registers are one statement: nothing can come between
-                        sa_u32x4 dk;
-#define SA_TAKE(N) asm volatile("s_waitcnt vmcnt(" #N ")\n\tv_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"   \
-                                : "=&v"(dk.x), "=&v"(dk.y), "=&v"(dk.z), "=&v"(dk.w)                                                      \
-                                : "v"(ring[k].x), "v"(ring[k].y), "v"(ring[k].z), "v"(ring[k].w) : "memory")
-                        if (ch == 0) SA_TAKE(0); else SA_TAKE(8);
-#undef SA_TAKE
                         if (r < lq) {
                             int run_total = 0, t = 1;
                             bool first = true;
                             while (j > 0) {
                                 // L = trailing zeros from column j-1 down = 2 * (LEFT moves) + (1 if an UP ends the run)
                                 const int sj = (j - 1) >> 6, jl = ((j - 1) & 63) + 1;
-                                sa_u32x4 d;
-                                if (first && ring_s[k] == sj) d = dk;
-                                else d = *reinterpret_cast<const sa_u32x4*>(tag_ptr(sj, r));
+                                uint4 d;
+                                if (first && ring_s[k] == sj) d = ring[k];
+                                else d = load_tags(sj, r);
                                 first = false;
                                 const uint64_t v0 = ((uint64_t)d.x << 32) | d.y;
                                 const uint64_t v1 = ((uint64_t)d.z << 32) | d.w;
@@ -293,12 +270,11 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_pair_kernel(const 
                         if (ch > 0) {
                             // the same row of the next piece, for the strip the walk is in now
                             const int sn = (max(j, 1) - 1) >> 6;
-                            const uint32_t* tp = tag_ptr(sn, r - 8);
-                            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ring[k]) : "v"(tp) : "memory");
+                            ring[k] = load_tags(sn, r - 8);
                             ring_s[k] = sn;
                         }
                     }
-                    if (act && ch <= ch0)
+                    if (act)
                         *reinterpret_cast<uint4*>(rec + SA_LONG_HEADER_BYTES + 16 * ch) = make_uint4(w[0], w[1], w[2], w[3]);
                 }
                 if (act) {
