@@ -38,8 +38,6 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
     // rows 0..63 of the spill area hold the direction rows of the low halves, rows 64..127 those of the high halves
     const __amdgpu_buffer_rsrc_t spill = __builtin_amdgcn_make_buffer_rsrc(
         P.spill + (size_t)blockIdx.x * P.spill_rows * 256, 0, P.spill_rows * 1024, SA_BUFFER_FLAGS);
-    const uint64_t sp_addr = reinterpret_cast<uint64_t>(P.spill + (size_t)blockIdx.x * P.spill_rows * 256);
-    const sa_u32x4 spill_words = {(uint32_t)sp_addr, (uint32_t)(sp_addr >> 32) & 0xffffu, P.spill_rows * 1024, SA_BUFFER_FLAGS};
     const uint32_t cpr = P.stride >> 4;   // 16-byte chunks per record
     const bool timed = P.phase_cycles != nullptr;
     unsigned long long tph[6] = {0, 0, 0, 0, 0, 0};
@@ -212,7 +210,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
                 const int base = half ? half_off : 0;
                 int matches = 0, gaps = 0;
 #define SA_TRACEBACK(WW)                                                                                   \
-    traceback_pk<WW, PROF_BYTES + 4>(lane, mlen, lq, lenp, spill_words, base, bw,                    \
+    traceback_pk<WW, PROF_BYTES + 4>(lane, mlen, lq, lenp, spill, base, bw,                    \
                                             stage + lane * SA_LDS_STAGE_DWORDS, matches, gaps)
                 if (wpr == 4) SA_TRACEBACK(4);
                 else if (wpr == 3) SA_TRACEBACK(3);

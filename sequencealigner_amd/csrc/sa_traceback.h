@@ -193,11 +193,10 @@ __device__ __forceinline__ uint32_t sa_ctz64_sat(uint64_t x) { // trailing zeros
 }
 
 // PCOL_LDS_OFFSET: byte address of column 0's residue code inside the workgroup's LDS (at least 3).
-//  * The direction words of a chunk (four rows) are requested two chunks ahead of their use, as instructions of
-//    their own with hand-counted waits: memory requests complete in the order they were issued, so with the
-//    requests of the two younger chunks allowed to stay in flight ("at most 8 outstanding") the chunk at hand
-//    has arrived.  Left to the compiler, the wait in front of a chunk's first use is for everything in flight,
-//    and the distance shrinks to what one chunk's work covers.
+//  * The direction words of a chunk (four rows) are requested two chunks ahead of their use, three register sets
+//    in turn.  (The compiler cannot follow the rotation through the loop and waits for everything in flight in
+//    front of a chunk's first use; hand-written requests with counted waits, "at most 8 outstanding", kept the two
+//    younger chunks in flight but changed nothing on the same machine with four waves per SIMD, and were dropped.)
 template <int W> struct SaDirWords;
 template <> struct SaDirWords<1> { typedef uint32_t type; };
 template <> struct SaDirWords<2> { typedef sa_u32x2 type; };
@@ -206,8 +205,8 @@ template <> struct SaDirWords<4> { typedef sa_u32x4 type; };
 
 template <int W, int PCOL_LDS_OFFSET>
 __device__ __forceinline__ void traceback_pk(const int lane, const int maxlen, const int lenq, const int lenp,
-                                             const sa_u32x4 spill_words, const int base_off,
-                                             uint32_t (&bw)[16],
+                                             const __amdgpu_buffer_rsrc_t spill, const int base_off,
+                                             const uint32_t (&bw)[16],
                                              uint32_t* __restrict__ stage_rec, int& matches_out, int& gaps_out) {
     typedef typename SaDirWords<W>::type words_t;
     struct Chunk { words_t d[4]; };
@@ -216,27 +215,17 @@ __device__ __forceinline__ void traceback_pk(const int lane, const int maxlen, c
     // code read for the row processed last and its UP flag, even and odd rows in turn; poisoned to begin with
     uint32_t pa0 = 0, pa1 = 0, pt0 = 1, pt1 = 1, b4_above = 0;
 
-    // the lane's residue registers are complete before the first hand-counted wait: a wait the compiler places
-    // for them inside the loop would be for everything in flight
-#pragma unroll
-    for (int k = 0; k < 16; k++) asm volatile("" : "+v"(bw[k]));
-
-    // Four requests, always: row indices past the end of the longest sequence are clamped.  (s_nop: the
-    // scalar offset may have been written by a vector instruction just before, see the residue requests.)
+    // row indices past the end of the longest sequence and chunk indices below 0 are clamped
     auto load_chunk = [&](int ch, Chunk& ck) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int r = min(4 * ch + k, maxlen - 1);   // wave-uniform
             const int row_off = base_off + r * 256 * W;
-            if (W == 4) asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(ck.d[k]) : "v"(lane_off), "s"(spill_words), "s"(row_off) : "memory");
-            else if (W == 3) asm volatile("s_nop 4\n\tbuffer_load_dwordx3 %0, %1, %2, %3 offen" : "+v"(ck.d[k]) : "v"(lane_off), "s"(spill_words), "s"(row_off) : "memory");
-            else if (W == 2) asm volatile("s_nop 4\n\tbuffer_load_dwordx2 %0, %1, %2, %3 offen" : "+v"(ck.d[k]) : "v"(lane_off), "s"(spill_words), "s"(row_off) : "memory");
-            else asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, %3 offen" : "+v"(ck.d[k]) : "v"(lane_off), "s"(spill_words), "s"(row_off) : "memory");
+            if constexpr (W == 4) ck.d[k] = __builtin_amdgcn_raw_buffer_load_b128(spill, lane_off, row_off, 0);
+            else if constexpr (W == 3) ck.d[k] = __builtin_amdgcn_raw_buffer_load_b96(spill, lane_off, row_off, 0);
+            else if constexpr (W == 2) ck.d[k] = __builtin_amdgcn_raw_buffer_load_b64(spill, lane_off, row_off, 0);
+            else ck.d[k] = __builtin_amdgcn_raw_buffer_load_b32(spill, lane_off, row_off, 0);
         }
-    };
-    // chunk `ck` has arrived when at most the requests of the two younger chunks are still in flight
-    auto arrived = [&](Chunk& ck) {
-        asm volatile("s_waitcnt vmcnt(8)" : "+v"(ck.d[0]), "+v"(ck.d[1]), "+v"(ck.d[2]), "+v"(ck.d[3]) : : "memory");
     };
 
     auto process = [&](int ch, const Chunk& ck) {
@@ -310,31 +299,21 @@ __device__ __forceinline__ void traceback_pk(const int lane, const int maxlen, c
     };
 
     // Three sets of registers take turns: step i requests chunk top - i into set i mod 3 and works on chunk
-    // top - i + 2, requested two steps earlier.  Every set is requested at one place and used at one place, and
-    // every statement that touches it reads and writes it in place: a value on its way from memory must not be
-    // copied to another register by the compiler, which does not know that it is still to come.  Requests are
-    // always issued (chunk indices below 0 are clamped to 0), so that the count in arrived() is the same for
-    // every chunk; what is left in flight is drained after the loop, before the registers get another use.
+    // top - i + 2, requested two steps earlier.
     Chunk c0, c1, c2;
-#pragma unroll
-    for (int k = 0; k < 4; k++) asm volatile("" : "=v"(c0.d[k]), "=v"(c1.d[k]), "=v"(c2.d[k]));
     const int top = (maxlen - 1) >> 2;
     for (int t = top; t >= -2; t -= 3) {
         load_chunk(max(t, 0), c0);
-        if (t + 2 <= top) { arrived(c1); process(t + 2, c1); }
+        if (t + 2 <= top) process(t + 2, c1);
         if (t >= -1) {
             load_chunk(max(t - 1, 0), c1);
-            if (t + 1 <= top) { arrived(c2); process(t + 1, c2); }
+            if (t + 1 <= top) process(t + 1, c2);
         }
         if (t >= 0) {
             load_chunk(max(t - 2, 0), c2);
-            arrived(c0);
             process(t, c0);
         }
     }
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(c0.d[k]), "+v"(c1.d[k]), "+v"(c2.d[k]) : : "memory");
     // the comparison row 0 left behind (read into the even-row pair)
     asm volatile("s_waitcnt lgkmcnt(0)\n\t"
                  "v_lshl_or_b32 %[ao], %[to], 8, %[ao]\n\t"
