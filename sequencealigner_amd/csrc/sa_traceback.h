@@ -175,7 +175,8 @@ __device__ __forceinline__ void traceback(const int lane, const int maxlen, cons
 //    also the output byte (2 * run + up).
 //  * Matches: the first sequence's residue codes lie in LDS two bytes apart (column c at pcol[2c]), so the byte
 //    address of the column a DIAG move consumes is s - L - 3, no shift; on an UP move bit 8 is set in the value
-//    read and the comparison with the row's residue fails.
+//    read and the comparison with the row's residue fails.  (Handing the value read to the next row's block, so
+//    that nothing waits for the LDS, made no difference on the same machine and was dropped.)
 //  * The dwords of a direction row are stored last first (dword m = columns 16(W-1-m) .. 16(W-1-m)+15), so that
 //    the register pair a 64-bit load fills is the 64-bit window value, lower columns in the upper half.
 //  * Gaps (the record counts the columns where sequence 1 has '-', the UP moves) are not counted per row but
@@ -212,8 +213,6 @@ __device__ __forceinline__ void traceback_pk(const int lane, const int maxlen, c
     struct Chunk { words_t d[4]; };
     uint32_t s = 2u * (uint32_t)lenp + 1u, matches = 0, ups = 0;
     const int lane_off = lane * W * 4;
-    // code read for the row processed last and its UP flag, even and odd rows in turn; poisoned to begin with
-    uint32_t pa0 = 0, pa1 = 0, pt0 = 1, pt1 = 1, b4_above = 0;
 
     // row indices past the end of the longest sequence and chunk indices below 0 are clamped
     auto load_chunk = [&](int ch, Chunk& ck) {
@@ -263,37 +262,30 @@ __device__ __forceinline__ void traceback_pk(const int lane, const int maxlen, c
                 }
                 L = (uint32_t)max((int)L, lo);
                 // t = L & 1 (1 = UP ends the run, 0 = DIAG); rest = s - L (DIAG: 2 * (column consumed + 1) + 1);
-                // a = pcol[rest - 3]; s = rest + 3t - 2, that is s - run - (2 for a DIAG move); byte k of the
-                // chunk's word = L.  One block of instructions: the LDS address is the state itself plus a
-                // constant that fits the instruction's offset field.  The value read is not waited for here:
-                // the row processed next (the row above) compares it, with bit 8 set when the move was UP, with
-                // the residue of this row -- by then the request before the newest one has arrived (LDS
-                // requests complete in order).  A lane's first row finds the poisoned initial values.  (Every
-                // output is written before the last input is read: none may share a register with an input.)
+                // a = pcol[rest - 3] | t << 8; matches += (a == residue of row r); s = rest + 3t - 2, that is
+                // s - run - (2 for a DIAG move); byte k of the chunk's word = L.  One block of instructions: the
+                // LDS address is the state itself plus a constant that fits the instruction's offset field, and
+                // the state is updated while the read is under way.  (Every output is written before the last
+                // input is read: none may share a register with an input.)
                 const uint32_t rest = s - L;
-#define SA_TB_ROW(K, ANEW, TNEW, AOLD, TOLD, BOLD, KOLD)                                                     \
+                uint32_t an_, tn_;
+#define SA_TB_ROW(K)                                                                                         \
     asm volatile("ds_read_u8 %[an], %[rest] offset:%[off]\n\t"                                               \
                  "v_and_b32 %[tn], 1, %[L]\n\t"                                                              \
                  "v_lshl_or_b32 %[packed], %[L], " #K " * 8, %[packed]\n\t"                                  \
                  "v_mad_u32_u24 %[s], %[tn], 3, %[rest]\n\t"                                                 \
                  "v_add_u32 %[s], -2, %[s]\n\t"                                                              \
-                 "s_waitcnt lgkmcnt(1)\n\t"                                                                  \
-                 "v_lshl_or_b32 %[ao], %[to], 8, %[ao]\n\t"                                                  \
-                 "v_cmp_eq_u32_sdwa vcc, %[ao], %[bo] src0_sel:DWORD src1_sel:BYTE_" #KOLD "\n\t"            \
+                 "s_waitcnt lgkmcnt(0)\n\t"                                                                  \
+                 "v_lshl_or_b32 %[an], %[tn], 8, %[an]\n\t"                                                  \
+                 "v_cmp_eq_u32_sdwa vcc, %[an], %[bo] src0_sel:DWORD src1_sel:BYTE_" #K "\n\t"               \
                  "v_addc_co_u32 %[m], vcc, 0, %[m], vcc"                                                     \
-                 : [an] "+&v"(ANEW), [tn] "+&v"(TNEW), [ao] "+&v"(AOLD), [packed] "+&v"(packed),             \
-                   [s] "=&v"(s), [m] "+&v"(matches)                                                          \
-                 : [to] "v"(TOLD), [bo] "v"(BOLD), [rest] "v"(rest), [L] "v"(L),                             \
-                   [off] "n"(PCOL_LDS_OFFSET - 3)                                                            \
+                 : [an] "=&v"(an_), [tn] "=&v"(tn_), [packed] "+&v"(packed), [s] "=&v"(s), [m] "+&v"(matches) \
+                 : [bo] "v"(b4), [rest] "v"(rest), [L] "v"(L), [off] "n"(PCOL_LDS_OFFSET - 3)                \
                  : "vcc")
-                if (k == 3) SA_TB_ROW(3, pa1, pt1, pa0, pt0, b4_above, 0);
-                else if (k == 2) SA_TB_ROW(2, pa0, pt0, pa1, pt1, b4, 3);
-                else if (k == 1) SA_TB_ROW(1, pa1, pt1, pa0, pt0, b4, 2);
-                else SA_TB_ROW(0, pa0, pt0, pa1, pt1, b4, 1);
+                if (k == 3) SA_TB_ROW(3); else if (k == 2) SA_TB_ROW(2); else if (k == 1) SA_TB_ROW(1); else SA_TB_ROW(0);
 #undef SA_TB_ROW
             }
         }
-        b4_above = b4;
         ups += __builtin_popcount(packed & 0x01010101u);
         stage_rec[2 + ch] = packed;
     };
@@ -314,12 +306,6 @@ __device__ __forceinline__ void traceback_pk(const int lane, const int maxlen, c
             process(t, c0);
         }
     }
-    // the comparison row 0 left behind (read into the even-row pair)
-    asm volatile("s_waitcnt lgkmcnt(0)\n\t"
-                 "v_lshl_or_b32 %[ao], %[to], 8, %[ao]\n\t"
-                 "v_cmp_eq_u32_sdwa vcc, %[ao], %[bo] src0_sel:DWORD src1_sel:BYTE_0\n\t"
-                 "v_addc_co_u32 %[m], vcc, 0, %[m], vcc"
-                 : [ao] "+v"(pa0), [m] "+v"(matches) : [to] "v"(pt0), [bo] "v"(b4_above) : "vcc");
     // body bytes past the last chunk are zero, so that equal inputs give equal records
     for (int z = ((maxlen - 1) >> 2) + 1; z < SA_LDS_STAGE_DWORDS - 2; z++) stage_rec[2 + z] = 0;
     matches_out = (int)matches;
