@@ -138,7 +138,8 @@ int sa_prepare_resident(sa_ctx* ctx, int schedule, uint64_t row_begin, uint64_t 
 int sa_run_resident(sa_ctx* ctx, float* kernel_ms);
 int sa_fetch_resident(sa_ctx* ctx, uint64_t first, uint64_t n, uint8_t* dst);
 /* tuning knobs of the peptide kernel: 64-pair tiles per work item, workgroups (waves)
- * per CU in a launch; 0 keeps the current value.  Until wg_per_cu is set the library launches
+ * per CU in a launch; 0 keeps the current value.  Until they are set the library takes 1 .. 16
+ * tiles per item from the size of the row range (at least 32 items per workgroup) and launches
  * as many workgroups per CU as registers and LDS let reside there, plus one. */
 int sa_set_tuning(sa_ctx* ctx, uint32_t tiles_per_item, uint32_t wg_per_cu);
 /* TRIANGULAR work normally runs on kernels that handle two first sequences per wave in packed

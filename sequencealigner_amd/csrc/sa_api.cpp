@@ -115,7 +115,7 @@ struct sa_ctx {
     uint32_t max_len = 64;
     hipStream_t compute = nullptr, copy = nullptr;
     // tuning
-    uint32_t tiles_per_item = 8;
+    uint32_t tiles_per_item = 0;   // 64-pair tiles per work item; 0 = from the size of the row range (see build_items)
     uint32_t wg_per_cu = 0;      // workgroups per CU in a launch; 0 = as many as are resident plus one that waits and fills the tail
     bool pairing = true;               // TRIANGULAR peptides: two first sequences per wave where the table allows it
     int64_t sprime_min = 0, sprime_max = 0;   // range of S' = S - 2*gap over the table: decides whether packed cells fit
@@ -254,6 +254,8 @@ bool uses_pairs(const sa_ctx* c) { return c->pairing && packed_cells_fit(c, is_l
 // paired (in/out): the caller allows the paired kernel / the items were built for it.  A row range in which
 // fewer than half of the first sequences find a partner of their length bucket runs unpaired: a wave of
 // the paired kernel with one first sequence does half the work for the same time.
+uint32_t grid_for(const sa_ctx* c);
+
 int build_items(sa_ctx* c, int schedule, uint64_t r0, uint64_t r1, std::vector<SaItem>& items, bool& paired) {
     items.clear();
     SaItem it;
@@ -270,7 +272,19 @@ int build_items(sa_ctx* c, int schedule, uint64_t r0, uint64_t r1, std::vector<S
     int rc = ensure_triangular(c);
     if (rc) return rc;
     // long sequences: one 64-pair tile is already milliseconds of work, and few items per workgroup leave a long tail
-    const uint32_t nb = c->nb, per = is_long(c) ? 1u : std::max(1u, c->tiles_per_item);
+    // peptides: many tiles per item spread the cost of an item's query profile (16 measured 1.5 % faster than 8 on
+    // 10^7 tiles), few keep the tail short when the range is small: at least 32 items per workgroup, at most 16 tiles
+    uint32_t per = 1;
+    if (!is_long(c)) {
+        per = c->tiles_per_item;
+        if (per == 0) {
+            const uint64_t tiles = sa_pair_count(c, schedule, r0, r1) / (uses_pairs(c) && paired ? 128 : 64);
+            const uint64_t want = tiles / ((uint64_t)grid_for(c) * 32);
+            per = 1;
+            while (per < 16 && per * 2 <= want) per *= 2;
+        }
+    }
+    const uint32_t nb = c->nb;
     // items of first sequence p (and, in the paired kernel, of a second one p2 > p that rides along)
     auto emit = [&](uint64_t p, uint32_t p2) {
         const uint32_t nvalid = (uint32_t)(c->nseq - 1 - p);
