@@ -277,10 +277,12 @@ def test_tuner_prints_its_two_tables(tmp_path):
 # the default where the table allows it) and unpaired (32-bit cells)
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,lo,hi,seed", [(700, 1, 64, 31), (900, 6, 50, 32), (257, 20, 21, 33), (130, 49, 56, 34)])
+@pytest.mark.parametrize("n,lo,hi,seed", [(700, 1, 64, 31), (900, 6, 50, 32), (257, 20, 21, 33), (130, 49, 56, 34),
+                                          (300, 45, 52, 35), (200, 52, 53, 36), (150, 63, 64, 37), (400, 1, 17, 38)])
 def test_paired_and_unpaired_kernels_give_identical_records(n, lo, hi, seed):
     """Few sequences and wide length ranges give buckets wider than one length (partners of different
-    lengths); 6..50 runs the 52-column variant, 1..64 and 49..56 the 64-column one."""
+    lengths); 6..50 runs the 52-column variant, 1..64 and 49..56 the 64-column one; 45..52 and 52..53 sit on
+    the border between the two, 63..64 fills the register row, 1..17 crosses the one-dword direction row."""
     seqs, _ = synth.generate(n, lo, hi, seed)
     al = sa.Aligner(max_seq_len=64)
     al.upload(seqs)
