@@ -3,7 +3,7 @@
 //
 // Every VGPR of the DP row holds the cell of (p1, q) in its low 16 bits and the cell of (p2, q)
 // in its high 16 bits.  Tags: 0 LEFT, 2 UP, 3 DIAG: with the newest column in the low bits of a
-// direction word a count-trailing-zeros finds a run of LEFT moves (sa_traceback.h, REV = 1).
+// direction word a count-trailing-zeros finds a run of LEFT moves (sa_traceback.h, traceback_pk).
 //
 // Cell format: 16*D + two tag fields.  Per four cells (two columns of both pairs): 2 add, 2 three-way
 // maxima, and, or, and-or for the operands of the cells to come, 2.5 on average for the tags.

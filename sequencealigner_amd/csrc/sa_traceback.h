@@ -17,12 +17,10 @@ typedef uint32_t sa_u32x4 __attribute__((ext_vector_type(4)));
 // ---------------------------------------------------------------- traceback
 // Bottom row first, four rows per chunk.  The direction words of a chunk are
 // requested two chunks ahead of their use (global spill area, coalesced).  A row
-// is W = ceil(ncols/16) dwords per lane.  Two layouts:
-//   REV = 0: the tag of column c is bits 2(c%16), 2(c%16)+1 of dword c/16, tags 0 LEFT,
-//            1 UP, 3 DIAG; a run of LEFT moves is found with count-leading-zeros;
-//   REV = 1: column c sits at bits 2(15 - c%16) of dword c/16 (lower columns higher up),
-//            tags 0 LEFT, 2 UP, 3 DIAG; the same walk with count-trailing-zeros.
-// In both, the zero count is 2 * (run of LEFT) + (1 if an UP ends it, 0 if a DIAG does).
+// is W = ceil(ncols/16) dwords per lane: the tag of column c is bits 2(c%16), 2(c%16)+1 of dword c/16,
+// tags 0 LEFT, 1 UP, 3 DIAG; a run of LEFT moves is found with count-leading-zeros, and the zero count
+// is 2 * (run of LEFT) + (1 if an UP ends it, 0 if a DIAG does).  (The paired kernel stores lower columns
+// higher up, tags 0 LEFT, 2 UP, 3 DIAG, and walks with count-trailing-zeros: traceback_pk below.)
 // base_off is the byte offset of the pair's rows inside the spill buffer.
 // Row residues (for counting matches): TRIANGULAR keeps the 64 residue codes of
 // the lane's second sequence in 16 registers (bw), ADJACENT reads them four at a
@@ -44,7 +42,7 @@ __device__ __forceinline__ uint32_t pick_word(const uint32_t (&W)[16], const int
     return v;
 }
 
-template <int MODE, int W, int REV = 0>
+template <int MODE, int W>
 __device__ __forceinline__ void traceback(const int lane, const int maxlen, const int lenq, const int lenp,
                                           const __amdgpu_buffer_rsrc_t spill, const int base_off,
                                           const uint32_t (&bw)[16], const uint8_t* __restrict__ brow,
@@ -94,23 +92,7 @@ __device__ __forceinline__ void traceback(const int lane, const int maxlen, cons
                 // is cut to 0 and the move is UP (left border).
                 int L;
                 const uint32_t sh = 0u - (uint32_t)j2;       // (32 or 64 - j2) modulo the width of the shift
-                if (REV) {
-                    if (W == 1) {
-                        const uint32_t x = ck.d[k].x >> (sh & 31);
-                        L = x ? __builtin_ctz(x) : 32;
-                    } else if (W == 2) {
-                        const uint64_t v = ((uint64_t)ck.d[k].x << 32) | ck.d[k].y;
-                        const uint64_t x = v >> (sh & 63);
-                        L = x ? __builtin_ctzll(x) : 64;
-                    } else {
-                        const uint64_t v0 = ((uint64_t)ck.d[k].x << 32) | ck.d[k].y;
-                        const uint64_t v1 = ((uint64_t)ck.d[k].z << 32) | ck.d[k].w;
-                        const bool upper = j2 > 64;
-                        const uint64_t x = (upper ? v1 : v0) >> (sh & 63);
-                        const int l0 = v0 ? __builtin_ctzll(v0) : 64;
-                        L = x ? __builtin_ctzll(x) : (upper ? j2 - 64 + l0 : 64);
-                    }
-                } else if (W == 1) {
+                if (W == 1) {
                     const uint32_t x = ck.d[k].x << (sh & 31);
                     L = x ? __builtin_clz(x) : 32;
                 } else if (W == 2) {
@@ -167,7 +149,8 @@ __device__ __forceinline__ void traceback(const int lane, const int maxlen, cons
 }
 
 // ---------------------------------------------------------------- traceback, paired peptide kernel
-// The same walk for the REV layout with fewer instructions per row.
+// The same walk for the paired kernel's layout (lower columns higher up, count-trailing-zeros), with fewer
+// instructions per row.
 //  * State s = 2 * (columns of sequence 1 still to the left) + 1.  With L = min(trailing zeros of the window, s)
 //    the run of LEFT moves is L & ~1 and the move that ends it is UP when L is odd: a walk that reaches the left
 //    border finds L = s, which is odd.  (On the border itself, s = 1, the shift amount 64 - 2 * columns wraps to
