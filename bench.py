@@ -176,7 +176,7 @@ def main():
     if rank == 0:
         k_ms = sum(kernel_ms) / max(1, len(kernel_ms))
         if hi > 64:
-            kernel = "sa_long_pair_kernel<3>"
+            kernel = "sa_long_pair_kernel<4>"
         else:
             kernel = "sa_peptide_pair_kernel<13, 4>" if hi <= 52 else "sa_peptide_pair_kernel<16, 4>"
         achieved = my_cells * OPS_PER_CELL / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0

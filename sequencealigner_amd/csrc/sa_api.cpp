@@ -357,11 +357,11 @@ int pair_groups(const sa_ctx* c) { return c->max_seq <= 52 ? 13 : 16; }
 uint32_t grid_for(const sa_ctx* c) {
     if (is_long(c)) {
         // 32-bit cells: two waves per SIMD (a third one spills registers inside the row loop: measured 1.8 vs
-        // 3.0 TCUPS).  Packed cells keep one register row and run three, as far as the LDS copies of the two first
+        // 3.0 TCUPS).  Packed cells keep one register row and run four, as far as the LDS copies of the two first
         // sequences allow.  The direction area of a workgroup is large, keep the total under 96 GiB of the 288.
         const uint64_t budget = 96ull << 30;
         uint64_t per_cu = 8;
-        if (uses_pairs(c)) per_cu = std::min<uint64_t>(12, (160u * 1024u) / (SA_LDS_PROF_BYTES + 64 + 2 * c->lslot));
+        if (uses_pairs(c)) per_cu = std::min<uint64_t>(16, (160u * 1024u) / (SA_LDS_PROF_BYTES + 64 + 2 * c->lslot));
         uint64_t g = std::min<uint64_t>((uint64_t)c->ncu * per_cu, budget / spill_bytes_per_wg(c));
         return (uint32_t)std::max<uint64_t>(1, g);
     }

@@ -297,5 +297,5 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_pair_kernel(const 
 }
 
 extern "C" void sa_launch_long_pair(const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream) {
-    hipLaunchKernelGGL((sa_long_pair_kernel<3>), dim3(grid), dim3(64), lds_bytes, stream, *p);
+    hipLaunchKernelGGL((sa_long_pair_kernel<4>), dim3(grid), dim3(64), lds_bytes, stream, *p);
 }
