@@ -30,6 +30,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
     // pcol[192 + c], pcol[256 + c]: those of the item's two first sequences
     constexpr int PS = SA_PAIR_PROF_STRIDE(NG);          // dwords between profile rows
     constexpr int PROF_BYTES = 21 * PS * 4;
+    constexpr int SD = SA_PAIR_STAGE_DWORDS(NG);         // dwords of staging area per lane
     uint8_t* const pcol = smem + PROF_BYTES;
     uint32_t* const stage = reinterpret_cast<uint32_t*>(smem + PROF_BYTES + 2 * SA_LDS_EMASK_BYTES);
     const int lane = threadIdx.x;
@@ -116,7 +117,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
             // loads, so nothing in it waits for the direction stores to be acknowledged.  (With the residues
             // loaded from memory row by row, every wait for them was also a wait for the stores of the row
             // before: requests complete in order.)
-            uint8_t* const qres = reinterpret_cast<uint8_t*>(stage + lane * SA_LDS_STAGE_DWORDS + 2);
+            uint8_t* const qres = reinterpret_cast<uint8_t*>(stage + lane * SD + 2);
             {
                 const uint4* src = reinterpret_cast<const uint4*>(P.codes_s + (size_t)sidx * SA_LP);
                 uint2* dst = reinterpret_cast<uint2*>(qres);
@@ -210,8 +211,8 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
                 const int base = half ? half_off : 0;
                 int matches = 0, gaps = 0;
 #define SA_TRACEBACK(WW)                                                                                   \
-    traceback_pk<WW, PROF_BYTES + 4>(lane, mlen, lq, lenp, spill, base, bw,                    \
-                                            stage + lane * SA_LDS_STAGE_DWORDS, matches, gaps)
+    traceback_pk<WW, PROF_BYTES + 4, SD>(lane, mlen, lq, lenp, spill, base, bw,                    \
+                                            stage + lane * SD, matches, gaps)
                 if (wpr == 4) SA_TRACEBACK(4);
                 else if (wpr == 3) SA_TRACEBACK(3);
                 else if (wpr == 2) SA_TRACEBACK(2);
@@ -219,8 +220,8 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
 #undef SA_TRACEBACK
                 SA_PHASE(4);
                 const int score = (half ? d2 : d1) + (lenp + lenq) * P.gap;
-                stage[lane * SA_LDS_STAGE_DWORDS + 0] = (uint32_t)score;
-                stage[lane * SA_LDS_STAGE_DWORDS + 1] = (uint32_t)matches | ((uint32_t)gaps << 16);
+                stage[lane * SD + 0] = (uint32_t)score;
+                stage[lane * SD + 1] = (uint32_t)matches | ((uint32_t)gaps << 16);
                 __syncthreads();
 
                 // ------------------------------------------- records, 16 B per lane store
@@ -232,7 +233,10 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
                     const int ract = __shfl((int)act, rec, 64);
                     if (ract) {
                         // written once and not read again on the device: kept out of the way of the direction rows
-                        const sa_u32x4 v = *reinterpret_cast<const sa_u32x4*>(stage + rec * SA_LDS_STAGE_DWORDS + ch * 4);
+                        // (two 8-byte reads: a lane's part of the staging area is 8-byte aligned)
+                        const uint2 va = *reinterpret_cast<const uint2*>(stage + rec * SD + ch * 4);
+                        const uint2 vb = *reinterpret_cast<const uint2*>(stage + rec * SD + ch * 4 + 2);
+                        const sa_u32x4 v = {va.x, va.y, vb.x, vb.y};
                         __builtin_nontemporal_store(v, reinterpret_cast<sa_u32x4*>(out_row + (uint64_t)rrel * P.stride + ch * 16));
                     }
                 }

@@ -176,7 +176,8 @@ __device__ __forceinline__ uint32_t sa_ctz64_sat(uint64_t x) { // trailing zeros
     return min(fl, fh);
 }
 
-// PCOL_LDS_OFFSET: byte address of column 0's residue code inside the workgroup's LDS (at least 3).
+// PCOL_LDS_OFFSET: byte address of column 0's residue code inside the workgroup's LDS (at least 3);
+// STAGE_DWORDS: dwords of the lane's staging record (2 of header, the rest one byte per row).
 //  * The direction words of a chunk (four rows) are requested two chunks ahead of their use, three register sets
 //    in turn.  (The compiler cannot follow the rotation through the loop and waits for everything in flight in
 //    front of a chunk's first use; hand-written requests with counted waits, "at most 8 outstanding", kept the two
@@ -187,7 +188,7 @@ template <> struct SaDirWords<2> { typedef sa_u32x2 type; };
 template <> struct SaDirWords<3> { typedef sa_u32x3 type; };
 template <> struct SaDirWords<4> { typedef sa_u32x4 type; };
 
-template <int W, int PCOL_LDS_OFFSET>
+template <int W, int PCOL_LDS_OFFSET, int STAGE_DWORDS>
 __device__ __forceinline__ void traceback_pk(const int lane, const int maxlen, const int lenq, const int lenp,
                                              const __amdgpu_buffer_rsrc_t spill, const int base_off,
                                              const uint32_t (&bw)[16],
@@ -290,7 +291,7 @@ __device__ __forceinline__ void traceback_pk(const int lane, const int maxlen, c
         }
     }
     // body bytes past the last chunk are zero, so that equal inputs give equal records
-    for (int z = ((maxlen - 1) >> 2) + 1; z < SA_LDS_STAGE_DWORDS - 2; z++) stage_rec[2 + z] = 0;
+    for (int z = ((maxlen - 1) >> 2) + 1; z < STAGE_DWORDS - 2; z++) stage_rec[2 + z] = 0;
     matches_out = (int)matches;
     gaps_out = (int)ups;
 }
