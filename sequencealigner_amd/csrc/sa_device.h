@@ -36,10 +36,11 @@
 #define SA_LDS_STAGE_BYTES (64 * SA_LDS_STAGE_DWORDS * 4)
 #define SA_LDS_FIXED_BYTES (SA_LDS_PROF_BYTES + SA_LDS_EMASK_BYTES + SA_LDS_STAGE_BYTES)
 /* paired peptide kernel: the 52-column variant (ng = 13) keeps its profile rows 60 dwords apart (like 68, a stride
- * of 4 modulo 64 banks) and stages 72 bytes per lane (8 of header, 64 of residues or record rows: its records are
- * 64 bytes), which lets 16 workgroups share a CU's 160 KiB; the 64-column variant fits 14 */
+ * of 4 modulo 64 banks); both variants stage 72 bytes per lane (8 of header, 64 of residues or record rows; the
+ * last 8 bytes of an 80-byte record are padding and are not staged).  16 workgroups of the 52-column variant
+ * share a CU's 160 KiB, 15 of the 64-column one. */
 #define SA_PAIR_PROF_STRIDE(ng) ((ng) <= 13 ? 60 : SA_PROF_STRIDE)
-#define SA_PAIR_STAGE_DWORDS(ng) ((ng) <= 13 ? 18 : SA_LDS_STAGE_DWORDS)
+#define SA_PAIR_STAGE_DWORDS(ng) 18
 #define SA_PAIR_LDS_BYTES(ng) (21 * SA_PAIR_PROF_STRIDE(ng) * 4 + 2 * SA_LDS_EMASK_BYTES + 64 * SA_PAIR_STAGE_DWORDS(ng) * 4)
 
 /* One unit of work pulled from the device-side queue (32 bytes).

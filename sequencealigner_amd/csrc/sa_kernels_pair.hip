@@ -235,7 +235,8 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
                         // written once and not read again on the device: kept out of the way of the direction rows
                         // (two 8-byte reads: a lane's part of the staging area is 8-byte aligned)
                         const uint2 va = *reinterpret_cast<const uint2*>(stage + rec * SD + ch * 4);
-                        const uint2 vb = *reinterpret_cast<const uint2*>(stage + rec * SD + ch * 4 + 2);
+                        uint2 vb = make_uint2(0u, 0u);      // bytes 72 .. 79 of an 80-byte record: padding
+                        if (ch * 4 + 2 < (uint32_t)SD) vb = *reinterpret_cast<const uint2*>(stage + rec * SD + ch * 4 + 2);
                         const sa_u32x4 v = {va.x, va.y, vb.x, vb.y};
                         __builtin_nontemporal_store(v, reinterpret_cast<sa_u32x4*>(out_row + (uint64_t)rrel * P.stride + ch * 16));
                     }
