@@ -279,7 +279,7 @@ int build_items(sa_ctx* c, int schedule, uint64_t r0, uint64_t r1, std::vector<S
         per = c->tiles_per_item;
         if (per == 0) {
             const uint64_t tiles = sa_pair_count(c, schedule, r0, r1) / (uses_pairs(c) && paired ? 128 : 64);
-            const uint64_t want = tiles / ((uint64_t)grid_for(c) * 32);
+            const uint64_t want = tiles / (std::max<uint64_t>(1, grid_for(c)) * 32);
             per = 1;
             while (per < 16 && per * 2 <= want) per *= 2;
         }

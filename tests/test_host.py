@@ -313,3 +313,15 @@ def test_c_dataset_tool_mega_layout(tmp_path):
 def test_c_dataset_tool_usage_error():
     import subprocess
     assert subprocess.run([DATASET_TOOL, "nothing"], capture_output=True).returncode == 2
+
+
+def test_tiles_per_item_follow_the_size_of_the_row_range():
+    """Unless set, a work item takes 1 .. 16 tiles: 16 when the range holds at least 32 such items per workgroup,
+    fewer on small ranges (a host-only context counts 256 CUs)."""
+    seqs, _ = synth.generate(3000, 20, 21, 5)
+    al = sa.Aligner(device=sa.DEVICE_NONE)
+    al.upload(seqs)
+    small = al.work_items(sa.TRIANGULAR, 0, 2999)
+    assert max(int(it[2]) for it in small.tolist()) == 1          # 4.5 M pairs: 35 000 tiles for 4 000 workgroups
+    al.set_tuning(tiles_per_item=4)
+    assert max(int(it[2]) for it in al.work_items(sa.TRIANGULAR, 0, 2999).tolist()) == 4
