@@ -572,3 +572,33 @@ def test_half_precision_three_way_maximum_orders_like_unsigned_integers():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=100)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "mismatches 0" in out.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(30))
+def test_random_tables_gaps_and_lengths(seed):
+    """Seeded sweep over what the callers may pass: an asymmetric substitution table drawn from a random range,
+    a gap penalty of -1 .. -12, an alphabet of 2 .. 20 letters, peptide or long sequences.  Whichever kernel the
+    library picks for the combination (packed 16-bit cells or 32-bit cells), records equal the checker's on both
+    schedules."""
+    rng = random.Random(1000 + seed)
+    gap = -rng.randint(1, 12)
+    lo_s = rng.randint(-12, 2)
+    hi_s = lo_s + rng.randint(1, 24)
+    matrix = [rng.randint(lo_s, hi_s) for _ in range(400)]
+    letters = ALPHABET[: rng.randint(2, 20)]
+    long_case = seed % 3 == 2
+    lo, hi = (rng.randint(65, 90), rng.randint(91, 420)) if long_case else (rng.randint(1, 30), rng.randint(31, 64))
+    n = rng.randint(70, 130) if long_case else rng.randint(100, 260)
+    seqs = ["".join(rng.choice(letters) for _ in range(rng.randint(lo, hi))) for _ in range(n)]
+    al = sa.Aligner(gap=gap, matrix=matrix, max_seq_len=max(64, hi))
+    al.upload(seqs)
+    rec = al.align(sa.TRIANGULAR)
+    pairs = _tri_pairs(n, 0, n - 1)
+    assert len(rec) == len(pairs)
+    pick = sorted(rng.sample(range(len(pairs)), min(len(pairs), 500 if long_case else 3000)))
+    _check_pairs(al, rec[pick], [pairs[k] for k in pick], gap=gap, matrix=matrix)
+    adj = al.align(sa.ADJACENT)
+    assert len(adj) == n - 1
+    _check_pairs(al, adj, [(k, k + 1) for k in range(n - 1)], gap=gap, matrix=matrix)
+    al.close()
