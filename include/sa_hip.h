@@ -75,7 +75,9 @@ typedef struct {
  * (include/thread.h:87-114) and init_scoring_matrix (include/scoring.h:15-52).
  * S is the 20x20 substitution matrix indexed [sequence-1 residue][sequence-2
  * residue] in SA_ALPHABET order (include/seqalign.h:55); NULL selects the
- * reference's BLOSUM50.  gap is the linear gap penalty (include/user.h:13). */
+ * reference's BLOSUM50.  gap is the linear gap penalty (include/user.h:13).
+ * SA_ERR_ARG when max_seq_len * max|S - 2*gap| >= 2^29: the cells of the DP are 32-bit (the reference's are too,
+ * include/seqalign.h:18) and keep two tag bits. */
 int sa_init(sa_ctx** ctx, const int32_t* S, int32_t gap, uint32_t max_seq_len, int device);
 void sa_destroy(sa_ctx* ctx);
 const char* sa_strerror(int code);

@@ -374,8 +374,10 @@ int sa_oracle_run_file(const char* in_path, const char* out_path, int schedule, 
     oracle_table t;
     if (load_table(in_path, 0, &t) != 0) return -1;
     int maxlen = 1;
+    size_t maxextra = 0;
     for (size_t k = 0; k < t.n; k++) {
         if (t.rows[k].len > maxlen) maxlen = t.rows[k].len;
+        if (strlen(t.rows[k].extra) > maxextra) maxextra = strlen(t.rows[k].extra);
         if (t.rows[k].len == 0) { free_table(&t); return -3; }
     }
     uint64_t total = 0;
@@ -390,7 +392,9 @@ int sa_oracle_run_file(const char* in_path, const char* out_path, int schedule, 
     if (out_path) {
         fd = open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
         if (fd < 0) { free_table(&t); return -4; }
-        wbuf = (char*)malloc(WBUF + 4 * (size_t)maxlen + 1024);
+        /* room for one more row past the flush mark: two sequences, two aligned strings of up to
+         * len1 + len2 columns, two pass-through fields, numbers and punctuation */
+        wbuf = (char*)malloc(WBUF + 6 * (size_t)maxlen + 2 * maxextra + 128);
         memcpy(wbuf, header, sizeof(header) - 1);
         wpos = sizeof(header) - 1;
     }

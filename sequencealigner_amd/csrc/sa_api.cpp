@@ -526,6 +526,14 @@ int sa_similarity_bp(int32_t matches, int32_t columns) {
 int sa_init(sa_ctx** out, const int32_t* S, int32_t gap, uint32_t max_seq_len, int device) {
     if (!out || max_seq_len == 0) return SA_ERR_ARG;
     if (max_seq_len > SA_MAX_LONG_LEN) return SA_ERR_LENGTH;
+    {
+        // the 32-bit cells hold 4*D + tag with D <= max_seq_len * max(S - 2*gap): refuse tables that could wrap
+        int32_t dflt[400];
+        if (!S) sa_default_matrix(dflt);
+        int64_t low, top;
+        table_range(S ? S : dflt, gap, low, top);
+        if ((int64_t)max_seq_len * std::max<int64_t>(std::llabs(low), std::llabs(top)) >= (1ll << 29)) return SA_ERR_ARG;
+    }
     if (device == SA_DEVICE_NONE) {
         sa_ctx* h = new (std::nothrow) sa_ctx();
         if (!h) return SA_ERR_NOMEM;
@@ -645,6 +653,7 @@ int sa_upload(sa_ctx* c, const uint8_t* codes, const uint64_t* offs, const uint3
         for (uint64_t s = lo; s < hi; s++) c->len[s] = (uint16_t)lens[s];
     });
     c->len_suffix.clear();
+    ensure_suffix(c);      // here, not lazily: sa_cell_count / sa_shard_rows take a const context and may run on any thread
     if (c->device == SA_DEVICE_NONE) {
         // no device to read the slots back from: a host-only context keeps them itself
         c->slots_host.assign((size_t)(nseq + 2) * lslot, SA_PAD_CODE);
@@ -698,7 +707,6 @@ uint64_t sa_pair_count(const sa_ctx* c, int schedule, uint64_t r0, uint64_t r1) 
 
 uint64_t sa_cell_count(const sa_ctx* c, int schedule, uint64_t r0, uint64_t r1) {
     if (!c || r1 <= r0) return 0;
-    if (schedule != SA_SCHEDULE_ADJACENT) ensure_suffix(const_cast<sa_ctx*>(c));     // a cache, built once
     uint64_t cells = 0;
     for (uint64_t i = r0; i < r1; i++) {
         if (schedule == SA_SCHEDULE_ADJACENT) cells += (uint64_t)c->len[i] * c->len[i + 1];

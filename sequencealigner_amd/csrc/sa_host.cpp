@@ -411,8 +411,11 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
     uint64_t* const offs = offs_mem.get();
     uint32_t* const lens = lens_mem.get();
     uint64_t total = 0;
+    uint32_t longest_seq = 0, longest_other = 0;     // what the row buffers of the host formatter are sized by
     for (uint64_t s = 0; s < n; s++) {
         const Row& r = tab.rows[s];
+        longest_seq = std::max(longest_seq, r.len);
+        longest_other = std::max(longest_other, r.other_len);
         if (r.len == 0 || r.len > max_len) {
             err = "row " + std::to_string(s + 2) + ": sequence length " + std::to_string(r.len) + " outside 1.." + std::to_string(max_len);
             cleanup(); if (out_fd >= 0) close(out_fd);
@@ -447,7 +450,8 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
             rc = sa_upload(ctx[(size_t)d], codes, offs, lens, n);
             if (rc) { cleanup(); if (out_fd >= 0) close(out_fd); return fail(rc); }
         }
-        const bool text_mode = st->mode_write && st->device_format;
+        // rows of more columns than the device formatter's layout holds are formatted on the host (any column count)
+        const bool text_mode = st->mode_write && st->device_format && L.ncols <= 32;
         if (text_mode) {
             // the rows are written on the GPU: it needs the layout and the pass-through text of every input row
             sa_text_layout tl;
@@ -462,7 +466,7 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
                 for (uint64_t s = lo; s < hi; s++) memcpy(obytes.data() + ooff[s], tab.rows[s].other, tab.rows[s].other_len);
             });
             for (int d = 0; d < ndev && rc == SA_OK; d++) {
-                rc = L.ncols <= 32 ? sa_set_text_layout(ctx[(size_t)d], &tl) : SA_ERR_ARG;
+                rc = sa_set_text_layout(ctx[(size_t)d], &tl);
                 if (rc == SA_OK) rc = sa_upload_passthrough(ctx[(size_t)d], obytes.data(), ooff.data(), n);
             }
             if (rc) { cleanup(); if (out_fd >= 0) close(out_fd); return fail(rc); }
@@ -502,7 +506,10 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
         uint64_t file_off = strlen(st->write_csv_header);       // where the next chunk's text starts in the file
         int cur_set = 0;
         std::thread text_writer;          // text submissions: the writer of the previous chunk
-        const size_t row_bound = 4 * (size_t)st->max_seq_len + 2 * 256 + L.part[0].size() + L.part[1].size() + L.part[2].size() + 64;
+        // longest possible row: both sequences, both aligned strings (at most len1 + len2 columns each), the two
+        // pass-through fields, the format parts, five numbers of at most 12 characters, separators and the newline
+        const size_t row_bound = 6 * (size_t)longest_seq + 2 * (size_t)longest_other + L.part[0].size() + L.part[1].size() +
+                                 L.part[2].size() + 5 * 12 + L.ncols + 1;
 
         size_t next_submit = 0;
         auto submit_more = [&]() -> int {

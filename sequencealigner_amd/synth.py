@@ -2,7 +2,7 @@
 
 One splitmix64 stream per set; per sequence: len = lo + next() % (hi - lo + 1),
 each residue ALPHABET[next() % 20], label = next() & 1.  The same recipe is
-implemented in C by the host tool (tools/sa_synth.c) so both produce the same file.
+implemented in C by the host tool (sequencealigner_amd/csrc/sa_dataset.c) so both produce the same file.
 """
 import numpy as np
 

@@ -515,6 +515,59 @@ def test_small_and_ragged_files_in_both_formatting_modes(tmp_path, text, schedul
     assert got.read_bytes() == want.read_bytes()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("device_format", [0, 1])
+def test_long_labels_and_worst_case_gap_counts(tmp_path, device_format):
+    """Rows far longer than the reference's MAX_CSV_LINE: a 1 KB pass-through field, and alignments of
+    len1 + len2 columns (W...W against C...C with gap -1 never pairs two residues), on the host
+    formatter and on the device formatter."""
+    seqs = [b"W" * 63, b"C" * 63, b"W" * 62, b"C" * 1, b"W" * 63, b"C" * 63]
+    labels = ["x" * 1024, "y", "z" * 700, "", "q" * 1000, "r" * 1023]
+    src = tmp_path / "in.csv"
+    synth.write_csv(str(src), seqs, labels)
+    for schedule in (sa.ADJACENT, sa.TRIANGULAR):
+        want, got = tmp_path / "oracle.csv", tmp_path / "gpu.csv"
+        oracle_lib.run_file(str(src), str(want), schedule, threads=2, gap=-1)
+        sa.run_csv(str(src), str(got), schedule, gap_penalty=-1, device_format=device_format)
+        assert got.read_bytes() == want.read_bytes()
+    # the same with long sequences (two bytes per record row)
+    seqs = [b"W" * 300, b"C" * 299, b"W" * 120, b"C" * 300]
+    labels = ["k" * 2000, "l", "m" * 1500, "n" * 3]
+    synth.write_csv(str(src), seqs, labels)
+    want, got = tmp_path / "oracle2.csv", tmp_path / "gpu2.csv"
+    oracle_lib.run_file(str(src), str(want), sa.TRIANGULAR, threads=2, gap=-1)
+    sa.run_csv(str(src), str(got), sa.TRIANGULAR, gap_penalty=-1, device_format=device_format, max_seq_len=301)
+    assert got.read_bytes() == want.read_bytes()
+
+
+@pytest.mark.gpu
+def test_more_output_columns_than_the_device_formatter_holds_fall_back_to_the_host(tmp_path):
+    """READ_CSV_COLS 15 gives 2*15 + 2 + 4 = 36 output columns; the device formatter's layout holds 32, the
+    driver then formats on the host (the reference has no such limit)."""
+    rng = random.Random(3)
+    rows = []
+    for k in range(40):
+        seq = "".join(rng.choice(ALPHABET) for _ in range(rng.randint(3, 40)))
+        rows.append(",".join(["c%d_%d" % (k, c) for c in range(7)] + [seq] + ["d%d_%d" % (k, c) for c in range(7)]))
+    src = tmp_path / "in.csv"
+    src.write_text("h" + ",h" * 14 + "\n" + "\n".join(rows) + "\n")
+    st = sa.default_settings()
+    st.read_csv_cols, st.read_csv_seq_pos = 15, 7
+    st.write_csv_header = (",".join("o%d" % c for c in range(36)) + "\n").encode()
+    out = tmp_path / "out.csv"
+    sa.run_csv(str(src), str(out), sa.ADJACENT, settings=st)
+    lines = out.read_text().split("\n")
+    assert len(lines) == 41 and lines[-1] == ""
+    for k, line in enumerate(lines[1:-1]):
+        s1, s2 = rows[k].split(",")[7], rows[k + 1].split(",")[7]
+        a1, a2, r = oracle_lib.align(s1, s2)
+        # the reference prints the first pass-through column of each row in every pair of free columns (include/csv.h:91-95)
+        f = line.split(",")
+        assert f[0] == s1 and f[1] == s2 and f[2] == "c%d_0" % k and f[3] == "c%d_0" % (k + 1)
+        assert f[4] == str(r.score) and f[5] == "\"('%s'" % a1.decode()
+        assert len(f) == 37          # the alignment column holds one comma
+
+
 def _text_rows(al, pairs, labels):
     rows = []
     for i, j in pairs:
