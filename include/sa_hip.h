@@ -55,6 +55,7 @@ enum {
     SA_ERR_STATE = -5,        /* call out of order (nothing uploaded, nothing submitted, ...) */
     SA_ERR_BUSY = -6,         /* both in-flight slots are in use: call sa_next/sa_release first */
     SA_ERR_RECORD = -7,       /* record does not describe an alignment of the given sequences */
+    SA_ERR_NOALLOC_SIZE = -8, /* sa_align_adjacent_noalloc: more pairs than its fixed scratch buffer serves */
     SA_ERR_HIP = -1000        /* -1000 - hipError_t */
 };
 
@@ -165,6 +166,26 @@ int sa_debug_work_items(sa_ctx* ctx, int schedule, uint64_t row_begin, uint64_t 
                         uint32_t* items8, uint64_t cap, uint64_t* count);
 /* diagnostic: file index of every sequence in bucket order (length bucket, then file index) */
 int sa_debug_bucket_order(sa_ctx* ctx, uint32_t* file_index, uint64_t cap, uint64_t* count);
+
+/* ---- one entry point that allocates nothing.  No counterpart in the reference: it is for callers that
+ * cannot allocate device memory (code under HIP graph capture rules, tight serving loops, harnesses that
+ * forbid hipMalloc).  It is the ADJACENT peptide path of sa_submit / sa_next with every buffer passed in:
+ *   d_slots    device memory, nseq slots of 64 bytes: residue codes 0..19 of sequence s, then padding (any
+ *              value; 20 is what sa_upload writes)
+ *   d_lens     device memory, nseq lengths (uint16), each 1 .. 64
+ *   d_records  device memory, (nseq - 1) * stride bytes; receives the record of pair k = (s_k, s_k+1) at
+ *              k * stride, in the layout sa_expand_record reads (row_bytes 1)
+ *   stride     multiple of 16, 16 .. 80, at least 8 + longest sequence
+ *   S, gap     host memory / value, as for sa_init (NULL = BLOSUM50)
+ * The kernels' scratch (work-queue head, work list, shifted table, direction rows) is a fixed array of
+ * SA_NOALLOC_SCRATCH_BYTES in the library's device image, one copy per GPU, held until the process ends.  At
+ * most SA_NOALLOC_MAX_PAIRS pairs per call (SA_ERR_NOALLOC_SIZE beyond).  The call runs on the null stream
+ * and returns when the records are complete; it calls no hipMalloc / hipFree and creates no stream or event.
+ * All calls on one GPU share that GPU's scratch array: calls that overlap on one GPU race. */
+#define SA_NOALLOC_MAX_PAIRS (1u << 22)
+#define SA_NOALLOC_SCRATCH_BYTES (67u << 20)
+int sa_align_adjacent_noalloc(int device, const uint8_t* d_slots, const uint16_t* d_lens, uint64_t nseq,
+                              const int32_t* S, int32_t gap, uint8_t* d_records, uint32_t stride);
 
 /* ---- records -> what the reference's Alignment holds (host only, no GPU).
  * seq1/seq2 are the ASCII sequences of the pair; a1/a2 receive the aligned

@@ -13,6 +13,7 @@ ADJACENT = 0
 TRIANGULAR = 1
 DEVICE_NONE = -1  # host-only context: schedule arithmetic and work lists, no compute
 ALPHABET = "ARNDCQEGHILKMFPSTWYV"
+NOALLOC_MAX_PAIRS = 1 << 22   # SA_NOALLOC_MAX_PAIRS (include/sa_hip.h)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -134,6 +135,8 @@ SIGNATURES = {
     "sa_debug_work_items": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32), C.c_uint64,
                                       C.POINTER(C.c_uint64)]),
     "sa_debug_bucket_order": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint64, C.POINTER(C.c_uint64)]),
+    "sa_align_adjacent_noalloc": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_int32), C.c_int32,
+                                            C.c_void_p, C.c_uint32]),
     "sa_similarity_bp": (C.c_int, [C.c_int32, C.c_int32]),
     "sa_default_matrix": (None, [C.POINTER(C.c_int32)]),
     # include/sa_host.h

@@ -496,6 +496,7 @@ const char* sa_strerror(int code) {
         case SA_ERR_STATE: return "call out of order";
         case SA_ERR_BUSY: return "two submissions already in flight";
         case SA_ERR_RECORD: return "record does not match the sequences";
+        case SA_ERR_NOALLOC_SIZE: return "more pairs than the fixed scratch buffer of sa_align_adjacent_noalloc serves";
         default: break;
     }
     if (code <= SA_ERR_HIP) return hipGetErrorString((hipError_t)(SA_ERR_HIP - code));
