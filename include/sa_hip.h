@@ -16,7 +16,7 @@
  * failure (sa_strerror() gives the text); the library owns all device and
  * pinned memory; the caller owns the sequences and whatever it does with the
  * records.  One context drives one GPU; a context may be used by one
- * submitting thread and one consuming thread.
+ * submitting thread (sa_submit*) and one consuming thread (sa_next*, sa_release) at the same time.
  */
 #ifndef SA_HIP_H
 #define SA_HIP_H
@@ -90,6 +90,15 @@ const char* sa_strerror(int code);
 int sa_encode(const char* seq, uint32_t len, uint8_t* codes);
 int sa_upload(sa_ctx* ctx, const uint8_t* codes, const uint64_t* offs, const uint32_t* lens, uint64_t nseq);
 
+/* One set of sequences on several GPUs: sa_clone_sequences gives `ctx` everything `donor` holds after its
+ * sa_upload -- the sequences, the tables of sa_prepare_schedule when they are built, the pass-through text and
+ * the text layout -- by device-to-device copies, with no second validation or bucketing on the host.  `ctx`
+ * must allow sequences as long as the donor's and have nothing in flight.
+ * sa_prepare_schedule builds what the first submission of a schedule would build (TRIANGULAR: the length-bucket
+ * order and the table of where each row's partners start), so that it is built once, before cloning. */
+int sa_prepare_schedule(sa_ctx* ctx, int schedule);
+int sa_clone_sequences(sa_ctx* ctx, sa_ctx* donor);
+
 /* ---- schedule arithmetic (no device work) */
 uint64_t sa_schedule_rows(const sa_ctx* ctx, int schedule);                 /* number of rows */
 uint64_t sa_pair_index(const sa_ctx* ctx, int schedule, uint64_t row);      /* canonical index of the row's first pair */
@@ -150,6 +159,10 @@ int sa_set_tuning(sa_ctx* ctx, uint32_t tiles_per_item, uint32_t wg_per_cu);
  * and longest sequence * max(S - 2*gap) <= 1983 when no sequence exceeds 64 residues; 1 .. 24 otherwise).  enable = 0 forces one first
  * sequence per wave, 32-bit cells (same results; for comparisons and tests).  Default: enabled. */
 int sa_set_pairing(sa_ctx* ctx, int enable);
+
+/* name of the fill + traceback kernel the context's most recent launch ran ("" before the first): the library picks
+ * between packed 16-bit and 32-bit cells, peptide and strip kernels from the table, the lengths and the row range */
+const char* sa_last_kernel(const sa_ctx* ctx);
 
 /* diagnostic: with enable != 0 the next launches accumulate shader cycles per kernel
  * phase (0 queue fetch, 1 profile build, 2 operand set-up, 3 fill, 4 traceback,

@@ -45,6 +45,8 @@ typedef struct {
     uint64_t pairs_per_submit;        /* 0 = batch_size * 4 (ADJACENT), batch_size * 64 (TRIANGULAR) */
     int32_t pairing;                  /* sa_set_pairing() of every context; default 1 */
     int32_t device_format;            /* 1 (default): rows of CSV text are written on the GPU (sa_submit_text); 0: records come back and host threads format them */
+    char scoring_matrix_file[4096];   /* SA_SCORING_MATRIX: file with the 20x20 substitution matrix (sa_load_matrix_file); empty = the
+                                         reference's BLOSUM50 literal (include/scoring.h:16-36) */
 } sa_settings;
 
 typedef struct {
@@ -60,6 +62,12 @@ typedef struct {
     double seconds_format;            /*           expanding and formatting records */
     double seconds_write;             /*           write() calls */
     char message[256];                /* error text when the return code is not 0 */
+    /* per device (index = position in sa_settings.devices): seconds its submit thread spent in sa_submit* (work lists
+     * included), and its drain thread waiting for the GPU, formatting records and waiting for its writer */
+    double device_submit[8];
+    double device_wait[8];
+    double device_format[8];
+    double device_write[8];
 } sa_run_report;
 
 void sa_settings_default(sa_settings* st);
@@ -68,6 +76,12 @@ int sa_settings_load(sa_settings* st, const char* path);
 /* the reference's checks on a settings file (scripts/config_schema.py:100-198); message receives the first problem */
 int sa_settings_validate(const sa_settings* st, char* message, uint32_t message_cap);
 int sa_run_csv(const sa_settings* st, sa_run_report* report);
+/* The scoring matrix as a setting: stands for the literal in init_scoring_matrix (include/scoring.h:15-52).  The file
+ * holds 400 integers, row-major, S[a][b] with a = residue of sequence 1 and b = residue of sequence 2 in the order
+ * ARNDCQEGHILKMFPSTWYV (include/scoring.h:6); integers are separated by blanks, commas, semicolons or line ends; lines
+ * that start with '#' and tokens that are single letters (a header row, a leading letter per row) are skipped.
+ * message (may be NULL) receives the problem when the result is not 0. */
+int sa_load_matrix_file(const char* path, int32_t S[400], char* message, uint32_t message_cap);
 
 #ifdef __cplusplus
 }

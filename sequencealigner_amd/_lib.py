@@ -19,7 +19,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def lib_path():
-    return os.path.join(_HERE, "libsa_hip.so")
+    # SA_HIP_LIBRARY names another build of the same library (A/B timing of two builds in one session)
+    return os.environ.get("SA_HIP_LIBRARY") or os.path.join(_HERE, "libsa_hip.so")
 
 
 class SaError(RuntimeError):
@@ -68,6 +69,7 @@ class Settings(C.Structure):
         ("pairs_per_submit", C.c_uint64),
         ("pairing", C.c_int32),
         ("device_format", C.c_int32),
+        ("scoring_matrix_file", C.c_char * 4096),
     ]
 
 
@@ -94,6 +96,10 @@ class RunReport(C.Structure):
         ("seconds_format", C.c_double),
         ("seconds_write", C.c_double),
         ("message", C.c_char * 256),
+        ("device_submit", C.c_double * 8),
+        ("device_wait", C.c_double * 8),
+        ("device_format", C.c_double * 8),
+        ("device_write", C.c_double * 8),
     ]
 
 
@@ -107,6 +113,8 @@ SIGNATURES = {
     "sa_strerror": (C.c_char_p, [C.c_int]),
     "sa_encode": (C.c_int, [C.c_char_p, C.c_uint32, _u8p]),
     "sa_upload": (C.c_int, [C.c_void_p, _u8p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_uint64]),
+    "sa_prepare_schedule": (C.c_int, [C.c_void_p, C.c_int]),
+    "sa_clone_sequences": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sa_schedule_rows": (C.c_uint64, [C.c_void_p, C.c_int]),
     "sa_pair_index": (C.c_uint64, [C.c_void_p, C.c_int, C.c_uint64]),
     "sa_pair_count": (C.c_uint64, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64]),
@@ -121,6 +129,7 @@ SIGNATURES = {
     "sa_run_resident": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "sa_fetch_resident": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, _u8p]),
     "sa_set_tuning": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
+    "sa_last_kernel": (C.c_char_p, [C.c_void_p]),
     "sa_set_pairing": (C.c_int, [C.c_void_p, C.c_int]),
     "sa_set_text_layout": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sa_upload_passthrough": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.c_uint64]),
@@ -144,6 +153,7 @@ SIGNATURES = {
     "sa_settings_load": (C.c_int, [C.POINTER(Settings), C.c_char_p]),
     "sa_settings_validate": (C.c_int, [C.POINTER(Settings), C.c_char_p, C.c_uint32]),
     "sa_run_csv": (C.c_int, [C.POINTER(Settings), C.POINTER(RunReport)]),
+    "sa_load_matrix_file": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32), C.c_char_p, C.c_uint32]),
 }
 
 
@@ -255,6 +265,14 @@ class Aligner:
             )
         )
         self.seqs = seqs
+
+    def prepare_schedule(self, schedule):
+        _check(self._lib.sa_prepare_schedule(self._ctx, schedule))
+
+    def clone_from(self, donor):
+        """Take the donor context's sequences and tables (device-to-device copies, no host work)."""
+        _check(self._lib.sa_clone_sequences(self._ctx, donor._ctx))
+        self.seqs = donor.seqs
 
     # -- schedule arithmetic
     def rows(self, schedule):
@@ -371,6 +389,10 @@ class Aligner:
         out = np.zeros((n, self.stride), dtype=np.uint8)
         _check(self._lib.sa_fetch_resident(self._ctx, first, n, out.ctypes.data_as(_u8p)))
         return out
+
+    def last_kernel(self):
+        """Name of the fill + traceback kernel the most recent launch ran."""
+        return self._lib.sa_last_kernel(self._ctx).decode()
 
     def phase_cycles(self, enable=True):
         """Shader-cycle totals per kernel phase of the previous timed launch; (re)arms the timers."""

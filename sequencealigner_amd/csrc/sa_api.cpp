@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 #include <time.h>
@@ -147,9 +148,11 @@ struct sa_ctx {
     int text_ring_pos = 0;
     uint32_t spill_grid = 0;
     Work slots[2];
+    std::mutex slot_mu;                // head / tail / inflight: one submitting and one consuming thread may overlap
     int head = 0, tail = 0, inflight = 0;
     Work resident;
     bool resident_ready = false;
+    const char* last_kernel = "";      // name of the fill + traceback kernel of the most recent launch
 };
 
 namespace {
@@ -421,16 +424,23 @@ int launch_work(sa_ctx* c, Work& w, bool timed) {
     if (timed) SA_HIP_TRY(hipEventRecord(w.t0, c->compute));
     P.lslot = c->lslot;
     P.bcol = (int32_t*)c->d_bcol.p;
-    if (is_long(c) && w.schedule == SA_SCHEDULE_TRIANGULAR && w.paired)
+    const bool tri = w.schedule == SA_SCHEDULE_TRIANGULAR;
+    if (is_long(c) && tri && w.paired) {
         // + 64: rows read table entries two groups ahead, up to 16 bytes past the last profile row; + 2 lslot: the two first sequences
         sa_launch_long_pair(&P, grid, SA_LDS_PROF_BYTES + 64 + 2 * c->lslot, c->compute);
-    else if (is_long(c))
-        sa_launch_long(w.schedule == SA_SCHEDULE_TRIANGULAR ? 0 : 1, &P, grid, SA_LDS_PROF_BYTES + 64 + c->lslot, c->compute);   // + 64: the row reads table entries two groups ahead, up to 16 bytes past the last profile row; + lslot: copy of the shared first sequence
-    else if (w.schedule == SA_SCHEDULE_TRIANGULAR && w.paired)
+        c->last_kernel = "sa_long_pair_kernel<4>";
+    } else if (is_long(c)) {
+        // + 64 as above; + lslot: copy of the shared first sequence
+        sa_launch_long(tri ? 0 : 1, &P, grid, SA_LDS_PROF_BYTES + 64 + c->lslot, c->compute);
+        c->last_kernel = tri ? "sa_long_kernel<0, 2>" : "sa_long_kernel<1, 2>";
+    } else if (tri && w.paired) {
         sa_launch_peptide_pair(pair_groups(c), &P, grid, SA_PAIR_LDS_BYTES(pair_groups(c)), c->compute);
-    else
-        sa_launch_peptide(w.schedule == SA_SCHEDULE_TRIANGULAR ? 0 : 1, (c->wg_per_cu == 0 || c->wg_per_cu > 8) ? 3 : 2, &P, grid,
-                          SA_LDS_FIXED_BYTES, c->compute);
+        c->last_kernel = pair_groups(c) <= 13 ? "sa_peptide_pair_kernel<13, 4>" : "sa_peptide_pair_kernel<16, 4>";
+    } else {
+        const int waves = (c->wg_per_cu == 0 || c->wg_per_cu > 8) ? 3 : 2;
+        sa_launch_peptide(tri ? 0 : 1, waves, &P, grid, SA_LDS_FIXED_BYTES, c->compute);
+        c->last_kernel = !tri ? "sa_peptide_kernel<1, 2>" : waves == 3 ? "sa_peptide_kernel<0, 3>" : "sa_peptide_kernel<0, 2>";
+    }
     SA_HIP_TRY(hipGetLastError());
     if (timed) SA_HIP_TRY(hipEventRecord(w.t1, c->compute));
     return SA_OK;
@@ -738,13 +748,74 @@ int sa_shard_rows(const sa_ctx* c, int schedule, uint32_t parts, uint64_t* bound
     return SA_OK;
 }
 
+int sa_prepare_schedule(sa_ctx* c, int schedule) {
+    if (!c || (schedule != SA_SCHEDULE_ADJACENT && schedule != SA_SCHEDULE_TRIANGULAR)) return SA_ERR_ARG;
+    if (c->nseq < 2) return SA_ERR_STATE;
+    if (schedule == SA_SCHEDULE_ADJACENT) return SA_OK;
+    if (c->device != SA_DEVICE_NONE) SA_HIP_TRY(hipSetDevice(c->device));
+    return ensure_triangular(c);
+}
+
+int sa_clone_sequences(sa_ctx* dst, sa_ctx* src) {
+    if (!dst || !src || dst == src) return SA_ERR_ARG;
+    if (src->nseq == 0 || dst->inflight || src->max_seq > dst->max_len) return SA_ERR_STATE;
+    if ((dst->device == SA_DEVICE_NONE) != (src->device == SA_DEVICE_NONE)) return SA_ERR_ARG;
+    dst->nseq = src->nseq; dst->min_seq = src->min_seq; dst->max_seq = src->max_seq;
+    if (dst->lslot != src->lslot) dst->spill_grid = 0;
+    dst->lslot = src->lslot; dst->row_bytes = src->row_bytes; dst->stride = src->stride;
+    dst->len = src->len; dst->len_suffix = src->len_suffix; dst->slots_host = src->slots_host;
+    dst->resident_ready = false;
+    dst->tri_ready = false;
+    const bool dev = dst->device != SA_DEVICE_NONE;
+    // device to device: between two GPUs the runtime takes the peer link (or stages through the host)
+    auto copy = [&](DevBuf& to, const DevBuf& from, size_t bytes) -> int {
+        int rc = to.reserve(std::max<size_t>(16, bytes));
+        if (rc) return rc;
+        if (bytes) SA_HIP_TRY(hipMemcpy(to.p, from.p, bytes, hipMemcpyDeviceToDevice));
+        return SA_OK;
+    };
+    int rc;
+    if (dev) {
+        SA_HIP_TRY(hipSetDevice(dst->device));
+        if ((rc = copy(dst->d_codes, src->d_codes, (size_t)(src->nseq + 2) * src->lslot))) return rc;
+        if ((rc = copy(dst->d_len, src->d_len, (src->nseq + 64) * 2))) return rc;
+    }
+    if (src->tri_ready) {
+        dst->nb = src->nb; dst->npad = src->npad; dst->bucket_width = src->bucket_width;
+        dst->bucket_base = src->bucket_base; dst->fi_sorted = src->fi_sorted; dst->cursor = src->cursor;
+        if (dev) {
+            const bool lng = src->lslot > SA_LP;
+            if ((rc = copy(dst->d_codes_t, src->d_codes_t, (size_t)src->lslot * src->npad))) return rc;
+            if ((rc = copy(dst->d_codes_s, src->d_codes_s, lng ? 16 : (size_t)src->npad * SA_LP))) return rc;
+            if ((rc = copy(dst->d_fi_sorted, src->d_fi_sorted, (size_t)src->npad * 4))) return rc;
+            if ((rc = copy(dst->d_len_sorted, src->d_len_sorted, (size_t)src->npad * 2))) return rc;
+            if ((rc = copy(dst->d_bucket_base, src->d_bucket_base, src->bucket_base.size() * 4))) return rc;
+            if ((rc = copy(dst->d_cursor, src->d_cursor, src->cursor.size() * 4))) return rc;
+        }
+        dst->tri_ready = true;
+    }
+    if (dev && src->other_set) {
+        if ((rc = copy(dst->d_other, src->d_other, src->d_other.cap))) return rc;
+        if ((rc = copy(dst->d_other_off, src->d_other_off, (src->nseq + 1) * 4))) return rc;
+        dst->max_other = src->max_other;
+        dst->other_set = true;
+    }
+    if (src->fmt_set) { dst->fmt = src->fmt; dst->fmt_set = true; }
+    return SA_OK;
+}
+
 int sa_submit(sa_ctx* c, int schedule, uint64_t r0, uint64_t r1) {
     if (!c || (schedule != SA_SCHEDULE_ADJACENT && schedule != SA_SCHEDULE_TRIANGULAR)) return SA_ERR_ARG;
     if (c->nseq < 2 || c->device == SA_DEVICE_NONE) return SA_ERR_STATE;
     if (r1 < r0 || r1 > sa_schedule_rows(c, schedule)) return SA_ERR_ARG;
-    if (c->inflight == 2) return SA_ERR_BUSY;
+    int head;
+    {
+        std::lock_guard<std::mutex> lock(c->slot_mu);
+        if (c->inflight == 2) return SA_ERR_BUSY;
+        head = c->head;
+    }
     SA_HIP_TRY(hipSetDevice(c->device));
-    Work& w = c->slots[c->head];
+    Work& w = c->slots[head];
     int rc = prepare_work(c, w, schedule, r0, r1, true);
     if (rc) return rc;
     if ((rc = launch_work(c, w, false))) return rc;
@@ -755,6 +826,7 @@ int sa_submit(sa_ctx* c, int schedule, uint64_t r0, uint64_t r1) {
     SA_HIP_TRY(hipEventRecord(w.copied, c->copy));
     w.busy = true;
     w.text_mode = false;
+    std::lock_guard<std::mutex> lock(c->slot_mu);
     c->head ^= 1;
     c->inflight++;
     return SA_OK;
@@ -762,9 +834,15 @@ int sa_submit(sa_ctx* c, int schedule, uint64_t r0, uint64_t r1) {
 
 int sa_next(sa_ctx* c, const uint8_t** records, uint64_t* first_pair, uint64_t* npairs) {
     if (!c || !records || !first_pair || !npairs) return SA_ERR_ARG;
-    if (c->inflight == 0) return SA_ERR_STATE;
-    Work& w = c->slots[c->tail];
+    int tail;
+    {
+        std::lock_guard<std::mutex> lock(c->slot_mu);
+        if (c->inflight == 0) return SA_ERR_STATE;
+        tail = c->tail;
+    }
+    Work& w = c->slots[tail];
     if (w.text_mode) return SA_ERR_STATE;
+    SA_HIP_TRY(hipSetDevice(c->device));
     SA_HIP_TRY(hipEventSynchronize(w.copied));
     *records = (const uint8_t*)w.host.p;
     *first_pair = w.first_pair;
@@ -774,6 +852,7 @@ int sa_next(sa_ctx* c, const uint8_t** records, uint64_t* first_pair, uint64_t* 
 
 int sa_release(sa_ctx* c) {
     if (!c) return SA_ERR_ARG;
+    std::lock_guard<std::mutex> lock(c->slot_mu);
     if (c->inflight == 0) return SA_ERR_STATE;
     c->slots[c->tail].busy = false;
     c->tail ^= 1;
@@ -835,9 +914,14 @@ int sa_submit_text(sa_ctx* c, int schedule, uint64_t r0, uint64_t r1) {
     if (!c || (schedule != SA_SCHEDULE_ADJACENT && schedule != SA_SCHEDULE_TRIANGULAR)) return SA_ERR_ARG;
     if (c->nseq < 2 || c->device == SA_DEVICE_NONE || !c->fmt_set || !c->other_set) return SA_ERR_STATE;
     if (r1 < r0 || r1 > sa_schedule_rows(c, schedule)) return SA_ERR_ARG;
-    if (c->inflight == 2) return SA_ERR_BUSY;
+    int head;
+    {
+        std::lock_guard<std::mutex> lock(c->slot_mu);
+        if (c->inflight == 2) return SA_ERR_BUSY;
+        head = c->head;
+    }
     SA_HIP_TRY(hipSetDevice(c->device));
-    Work& w = c->slots[c->head];
+    Work& w = c->slots[head];
     int rc = prepare_work(c, w, schedule, r0, r1, false);
     if (rc) return rc;
     if ((rc = launch_work(c, w, false))) return rc;
@@ -875,6 +959,7 @@ int sa_submit_text(sa_ctx* c, int schedule, uint64_t r0, uint64_t r1) {
     SA_HIP_TRY(hipEventRecord(w.kernel_done, c->compute));
     w.busy = true;
     w.text_mode = true;
+    std::lock_guard<std::mutex> lock(c->slot_mu);
     c->head ^= 1;
     c->inflight++;
     return SA_OK;
@@ -882,8 +967,13 @@ int sa_submit_text(sa_ctx* c, int schedule, uint64_t r0, uint64_t r1) {
 
 int sa_next_text(sa_ctx* c, const char** text, uint64_t* nbytes, uint64_t* first_pair, uint64_t* npairs) {
     if (!c || !text || !nbytes || !first_pair || !npairs) return SA_ERR_ARG;
-    if (c->inflight == 0) return SA_ERR_STATE;
-    Work& w = c->slots[c->tail];
+    int tail;
+    {
+        std::lock_guard<std::mutex> lock(c->slot_mu);
+        if (c->inflight == 0) return SA_ERR_STATE;
+        tail = c->tail;
+    }
+    Work& w = c->slots[tail];
     if (!w.text_mode) return SA_ERR_STATE;
     SA_HIP_TRY(hipSetDevice(c->device));
     SA_HIP_TRY(hipEventSynchronize(w.kernel_done));
@@ -951,6 +1041,8 @@ int sa_set_pairing(sa_ctx* c, int enable) {
     c->resident_ready = false;
     return SA_OK;
 }
+
+const char* sa_last_kernel(const sa_ctx* c) { return c ? c->last_kernel : ""; }
 
 int sa_debug_work_items(sa_ctx* c, int schedule, uint64_t r0, uint64_t r1, uint32_t* items8, uint64_t cap,
                         uint64_t* count) {

@@ -35,11 +35,14 @@
 #define SA_LDS_STAGE_DWORDS 20   /* per-lane staging record: 80 B */
 #define SA_LDS_STAGE_BYTES (64 * SA_LDS_STAGE_DWORDS * 4)
 #define SA_LDS_FIXED_BYTES (SA_LDS_PROF_BYTES + SA_LDS_EMASK_BYTES + SA_LDS_STAGE_BYTES)
-/* paired peptide kernel: the 52-column variant (ng = 13) keeps its profile rows 60 dwords apart (like 68, a stride
- * of 4 modulo 64 banks); both variants stage 72 bytes per lane (8 of header, 64 of residues or record rows; the
+/* paired kernels: profile rows 62 (52 columns, ng = 13) or 66 dwords apart, i.e. 2 banks modulo the 64 banks that
+ * an 8-byte LDS read sees: a lane reads its four table entries as two 8-byte reads, the 32 lanes of a read group hold
+ * up to 21 different row residues, and 21 windows of 2 banks fit side by side.  (With 16-byte reads and a stride of
+ * 4 banks only 16 rows fit: rows b and b + 16 shared their banks and 41 % of the LDS cycles were conflict cycles.)
+ * Both peptide variants stage 72 bytes per lane (8 of header, 64 of residues or record rows; the
  * last 8 bytes of an 80-byte record are padding and are not staged).  16 workgroups of the 52-column variant
  * share a CU's 160 KiB, 15 of the 64-column one. */
-#define SA_PAIR_PROF_STRIDE(ng) ((ng) <= 13 ? 60 : SA_PROF_STRIDE)
+#define SA_PAIR_PROF_STRIDE(ng) ((ng) <= 13 ? 62 : 66)
 #define SA_PAIR_STAGE_DWORDS(ng) 18
 #define SA_PAIR_LDS_BYTES(ng) (21 * SA_PAIR_PROF_STRIDE(ng) * 4 + 2 * SA_LDS_EMASK_BYTES + 64 * SA_PAIR_STAGE_DWORDS(ng) * 4)
 

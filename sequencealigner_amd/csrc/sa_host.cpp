@@ -11,6 +11,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <cerrno>
 #include <cstdio>
 #include <cstdlib>
@@ -335,9 +337,44 @@ int sa_settings_load(sa_settings* st, const char* path) {
         else if (k == "BATCH_SIZE") { if (num(x)) st->batch_size = (uint32_t)x; }
         else if (k == "SA_SCHEDULE") { if (num(x)) st->schedule = (int32_t)x; }
         else if (k == "SA_NUM_DEVICES") { if (num(x)) st->num_devices = (int32_t)x; }
+        else if (k == "SA_SCORING_MATRIX") { if (!parse_c_string(v, st->scoring_matrix_file, sizeof(st->scoring_matrix_file))) st->scoring_matrix_file[0] = 0; }
     }
     fclose(f);
     return rc;
+}
+
+int sa_load_matrix_file(const char* path, int32_t S[400], char* message, uint32_t cap) {
+    auto say = [&](const std::string& m) { if (message && cap) snprintf(message, cap, "%s", m.c_str()); return SA_ERR_ARG; };
+    if (!path || !S) return SA_ERR_ARG;
+    FILE* f = fopen(path, "r");
+    if (!f) return say(std::string("cannot open scoring matrix file: ") + strerror(errno));
+    char line[8192];
+    int count = 0;
+    bool bad = false;
+    std::string bad_token;
+    while (!bad && fgets(line, sizeof(line), f)) {
+        const char* p = line;
+        while (*p == ' ' || *p == '\t') p++;
+        if (*p == '#') continue;
+        while (*p) {
+            while (*p == ' ' || *p == '\t' || *p == ',' || *p == ';' || *p == '\r' || *p == '\n') p++;
+            if (!*p) break;
+            const char* tok = p;
+            while (*p && *p != ' ' && *p != '\t' && *p != ',' && *p != ';' && *p != '\r' && *p != '\n') p++;
+            const size_t len = (size_t)(p - tok);
+            if (len == 1 && ((*tok >= 'A' && *tok <= 'Z') || (*tok >= 'a' && *tok <= 'z') || *tok == '*')) continue;
+            char* e = nullptr;
+            const long v = strtol(tok, &e, 10);
+            if (e != p || v < -32768 || v > 32767) { bad = true; bad_token.assign(tok, len); break; }
+            if (count < 400) S[count] = (int32_t)v;
+            count++;
+        }
+    }
+    fclose(f);
+    if (bad) return say("scoring matrix file: '" + bad_token + "' is not an integer");
+    if (count != 400) return say("scoring matrix file holds " + std::to_string(count) + " integers, 400 (20 x 20) are needed");
+    if (message && cap) message[0] = 0;
+    return SA_OK;
 }
 
 int sa_settings_validate(const sa_settings* st, char* message, uint32_t cap) {
@@ -356,6 +393,11 @@ int sa_settings_validate(const sa_settings* st, char* message, uint32_t cap) {
     Layout L;
     std::string err;
     if (make_layout(st, L, err) != SA_OK) return say(err.c_str());
+    if (st->scoring_matrix_file[0]) {
+        int32_t S[400];
+        const int rc = sa_load_matrix_file(st->scoring_matrix_file, S, message, cap);
+        if (rc) return rc;
+    }
     if (message && cap) message[0] = 0;
     return SA_OK;
 }
@@ -383,8 +425,16 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
     // the reference's buffers hold sequences shorter than MAX_SEQ_LEN (NUL included, include/thread.h:27-29)
     const uint32_t max_len = st->max_seq_len ? st->max_seq_len - 1 : 0;
     if (max_len == 0 || max_len > SA_MAX_SEQ_LEN) { err = "MAX_SEQ_LEN must be between 2 and 4097"; return fail(SA_ERR_LENGTH); }
+    int32_t matrix[400];
+    const int32_t* S = nullptr;          // NULL: the library's BLOSUM50
+    if (st->scoring_matrix_file[0]) {
+        char msg[200];
+        rc = sa_load_matrix_file(st->scoring_matrix_file, matrix, msg, sizeof(msg));
+        if (rc) { err = msg; return fail(rc); }
+        S = matrix;
+    }
     for (int d = 0; d < ndev; d++) {
-        rc = sa_init(&ctx[(size_t)d], nullptr, st->gap_penalty, max_len, st->devices[d]);
+        rc = sa_init(&ctx[(size_t)d], S, st->gap_penalty, max_len, st->devices[d]);
         if (rc == SA_OK) rc = sa_set_pairing(ctx[(size_t)d], st->pairing);
         if (rc) { cleanup(); return fail(rc); }
     }
@@ -446,14 +496,14 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
 
     if (n >= 2) {
         const double tu0 = now_s();
-        for (int d = 0; d < ndev; d++) {
-            rc = sa_upload(ctx[(size_t)d], codes, offs, lens, n);
-            if (rc) { cleanup(); if (out_fd >= 0) close(out_fd); return fail(rc); }
-        }
+        const int schedule = st->schedule;
         // rows of more columns than the device formatter's layout holds are formatted on the host (any column count)
         const bool text_mode = st->mode_write && st->device_format && L.ncols <= 32;
-        if (text_mode) {
-            // the rows are written on the GPU: it needs the layout and the pass-through text of every input row
+        // The first context takes the sequences from the host (validation, slots, length tables; for TRIANGULAR the
+        // bucket order and cursor table; for rows written on the GPU the layout and the pass-through text); the
+        // others clone it device to device, all at once.
+        rc = sa_upload(ctx[0], codes, offs, lens, n);
+        if (rc == SA_OK && text_mode) {
             sa_text_layout tl;
             memset(&tl, 0, sizeof(tl));
             tl.ncols = L.ncols;
@@ -465,21 +515,28 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
             sa_parallel_for(n, 1 << 16, [&](uint64_t lo, uint64_t hi, unsigned) {
                 for (uint64_t s = lo; s < hi; s++) memcpy(obytes.data() + ooff[s], tab.rows[s].other, tab.rows[s].other_len);
             });
-            for (int d = 0; d < ndev && rc == SA_OK; d++) {
-                rc = sa_set_text_layout(ctx[(size_t)d], &tl);
-                if (rc == SA_OK) rc = sa_upload_passthrough(ctx[(size_t)d], obytes.data(), ooff.data(), n);
-            }
-            if (rc) { cleanup(); if (out_fd >= 0) close(out_fd); return fail(rc); }
+            rc = sa_set_text_layout(ctx[0], &tl);
+            if (rc == SA_OK) rc = sa_upload_passthrough(ctx[0], obytes.data(), ooff.data(), n);
         }
+        if (rc == SA_OK && ndev > 1) {
+            rc = sa_prepare_schedule(ctx[0], schedule);
+            std::vector<int> crc((size_t)ndev, SA_OK);
+            std::vector<std::thread> cl;
+            if (rc == SA_OK)
+                for (int d = 1; d < ndev; d++)
+                    cl.emplace_back([&, d]() { crc[(size_t)d] = sa_clone_sequences(ctx[(size_t)d], ctx[0]); });
+            for (auto& t : cl) t.join();
+            for (int d = 1; d < ndev && rc == SA_OK; d++) rc = crc[(size_t)d];
+        }
+        if (rc) { cleanup(); if (out_fd >= 0) close(out_fd); return fail(rc); }
         rep->seconds_upload = now_s() - tu0;
-        const int schedule = st->schedule;
         const uint64_t rows = sa_schedule_rows(ctx[0], schedule);
         rep->pairs = sa_pair_count(ctx[0], schedule, 0, rows);
         rep->cells = sa_cell_count(ctx[0], schedule, 0, rows);
         const uint32_t stride = sa_record_stride(ctx[0]);
         const uint32_t row_bytes = sa_record_row_bytes(ctx[0]);
 
-        // chunks of whole schedule rows; chunk k goes to device k % ndev, results are consumed in chunk order
+        // chunks of whole schedule rows; chunk k goes to device k % ndev, the text of chunk k follows that of chunk k-1
         // 262144 pairs at the default BATCH_SIZE: the best of the tuner's sweep (ADJACENT, writing on).  TRIANGULAR
         // submissions are whole rows of the schedule and find partners for the paired kernel inside a
         // submission: sixteen times as many pairs.
@@ -496,135 +553,214 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
             chunks.push_back({r0, r1});
             r0 = r1;
         }
-        int nthreads = st->format_threads > 0 ? st->format_threads : (int)std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
-        // two sets of format buffers: one is written to the file by a writer thread while the other is filled
-        std::vector<std::vector<char>> bufset[2] = {std::vector<std::vector<char>>((size_t)nthreads), std::vector<std::vector<char>>((size_t)nthreads)};
-        std::vector<size_t> usedset[2] = {std::vector<size_t>((size_t)nthreads), std::vector<size_t>((size_t)nthreads)};
-        std::thread writer[2];
-        std::atomic<bool> write_failed(false);
-        std::atomic<uint64_t> written(0);
-        uint64_t file_off = strlen(st->write_csv_header);       // where the next chunk's text starts in the file
-        int cur_set = 0;
-        std::thread text_writer;          // text submissions: the writer of the previous chunk
+        const size_t nchunks = chunks.size();
+        const int total_threads = st->format_threads > 0 ? st->format_threads : (int)std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
+        const int fthreads = std::max(1, total_threads / ndev);      // format threads of one device's drain thread
         // longest possible row: both sequences, both aligned strings (at most len1 + len2 columns each), the two
         // pass-through fields, the format parts, five numbers of at most 12 characters, separators and the newline
         const size_t row_bound = 6 * (size_t)longest_seq + 2 * (size_t)longest_other + L.part[0].size() + L.part[1].size() +
                                  L.part[2].size() + 5 * 12 + L.ncols + 1;
 
-        size_t next_submit = 0;
-        auto submit_more = [&]() -> int {
-            // keep up to two chunks in flight per device, in chunk order
-            while (next_submit < chunks.size() && next_submit < rep->chunks_done + 2 * (size_t)ndev) {
-                sa_ctx* c = ctx[next_submit % (size_t)ndev];
-                int r = text_mode ? sa_submit_text(c, schedule, chunks[next_submit].r0, chunks[next_submit].r1)
-                                  : sa_submit(c, schedule, chunks[next_submit].r0, chunks[next_submit].r1);
-                if (r == SA_ERR_BUSY) break;
-                if (r) return r;
-                next_submit++;
-            }
-            return SA_OK;
+        // ---- where a chunk's text goes in the file: known once every earlier chunk has reported its size
+        struct Order {
+            std::mutex m;
+            std::condition_variable cv;
+            std::vector<int64_t> size;          // -1: not known yet
+            std::vector<uint64_t> offset;       // offset[k] valid for k <= front
+            size_t front = 0;
+        } order;
+        order.size.assign(nchunks, -1);
+        order.offset.assign(nchunks + 1, strlen(st->write_csv_header));
+        std::atomic<int> err(SA_OK);
+        auto set_err = [&](int code) {
+            int none = SA_OK;
+            err.compare_exchange_strong(none, code);
+            { std::lock_guard<std::mutex> lk(order.m); }
+            order.cv.notify_all();
         };
-        for (size_t k = 0; k < chunks.size() && rc == SA_OK; k++) {
-            if ((rc = submit_more())) break;
-            sa_ctx* c = ctx[k % (size_t)ndev];
-            const uint8_t* recs = nullptr;
-            uint64_t first = 0, np = 0;
-            const double tw0 = now_s();
-            if (text_mode) {
-                const char* text = nullptr;
-                uint64_t nbytes = 0;
-                if ((rc = sa_next_text(c, &text, &nbytes, &first, &np))) break;
-                t_wait += now_s() - tw0;
-                // Finished rows: the slot is free again at once (the text sits in a buffer of the context that
-                // stays valid over the next call); a writer thread (with helpers) puts the slices of the text at
-                // their place in the file while the next submission is awaited.
-                if ((rc = sa_release(c))) break;
-                const double tw1 = now_s();
-                if (text_writer.joinable()) text_writer.join();
-                t_write += now_s() - tw1;
-                const uint64_t at = file_off;
-                file_off += nbytes;
-                text_writer = std::thread([text, nbytes, at, out_fd, &write_failed, &written]() {
-                    sa_parallel_for(nbytes, 1 << 22, [&](uint64_t lo, uint64_t hi, unsigned) {
-                        if (!pwrite_all(out_fd, text + lo, hi - lo, at + lo)) write_failed.store(true);
-                    });
-                    written.fetch_add(nbytes);
-                });
-                rep->chunks_done++;
-                continue;
+        auto publish = [&](size_t k, uint64_t nbytes) {
+            { std::lock_guard<std::mutex> lk(order.m);
+              order.size[k] = (int64_t)nbytes;
+              while (order.front < nchunks && order.size[order.front] >= 0) {
+                  order.offset[order.front + 1] = order.offset[order.front] + (uint64_t)order.size[order.front];
+                  order.front++;
+              } }
+            order.cv.notify_all();
+        };
+        auto offset_of = [&](size_t k, uint64_t& at) -> bool {     // false: the run has failed
+            std::unique_lock<std::mutex> lk(order.m);
+            order.cv.wait(lk, [&] { return order.front >= k || err.load() != SA_OK; });
+            if (order.front < k) return false;
+            at = order.offset[k];
+            return true;
+        };
+        std::atomic<bool> write_failed(false);
+        std::atomic<uint64_t> written(0);
+        std::atomic<uint64_t> chunks_done(0);
+
+        // ---- per device: one thread submits its chunks (work lists are built there), one drains them in order
+        struct Dev {
+            std::mutex m;
+            std::condition_variable cv;
+            size_t submitted = 0, consumed = 0;
+            bool submit_done = false;
+            double t_submit = 0, t_wait = 0, t_format = 0, t_write = 0;
+        };
+        std::vector<Dev> devs((size_t)ndev);
+        auto submit_loop = [&](int d) {
+            Dev& D = devs[(size_t)d];
+            sa_ctx* c = ctx[(size_t)d];
+            for (size_t k = (size_t)d; k < nchunks; k += (size_t)ndev) {
+                {   // at most two chunks of a context in flight
+                    std::unique_lock<std::mutex> lk(D.m);
+                    D.cv.wait(lk, [&] { return D.submitted - D.consumed < 2 || err.load() != SA_OK; });
+                }
+                if (err.load() != SA_OK) break;
+                const double ts = now_s();
+                const int r = text_mode ? sa_submit_text(c, schedule, chunks[k].r0, chunks[k].r1)
+                                        : sa_submit(c, schedule, chunks[k].r0, chunks[k].r1);
+                D.t_submit += now_s() - ts;
+                if (r) { set_err(r); break; }
+                { std::lock_guard<std::mutex> lk(D.m); D.submitted++; }
+                D.cv.notify_all();
             }
-            if ((rc = sa_next(c, &recs, &first, &np))) break;
-            t_wait += now_s() - tw0;
-            if (st->mode_write && np) {
-                const double tj0 = now_s();
-                if (writer[cur_set].joinable()) writer[cur_set].join();     // this set's previous contents are on disk
-                t_write += now_s() - tj0;
-                std::vector<std::vector<char>>& bufs = bufset[cur_set];
-                std::vector<size_t>& used = usedset[cur_set];
-                std::atomic<int> bad(0);
-                auto work = [&](int t) {
-                    const uint64_t lo = np * (uint64_t)t / (uint64_t)nthreads, hi = np * (uint64_t)(t + 1) / (uint64_t)nthreads;
-                    std::vector<char>& b = bufs[(size_t)t];
-                    if (b.size() < (hi - lo) * row_bound + 16) b.resize((hi - lo) * row_bound + 16);
-                    std::vector<char> a1(2 * (size_t)st->max_seq_len + 2), a2(2 * (size_t)st->max_seq_len + 2);
-                    size_t pos = 0;
-                    // pair (i, j) of the first record of this slice
-                    uint64_t i, j;
-                    if (schedule == SA_SCHEDULE_ADJACENT) { i = first + lo; j = i + 1; }
-                    else {
-                        i = chunks[k].r0;
-                        uint64_t idx = first + lo;
-                        while (sa_pair_index(c, schedule, i + 1) <= idx) i++;
-                        j = i + 1 + (idx - sa_pair_index(c, schedule, i));
-                    }
-                    for (uint64_t q = lo; q < hi; q++) {
-                        const Row& r1 = tab.rows[i];
-                        const Row& r2 = tab.rows[j];
-                        sa_alignment_stats s;
-                        if (sa_expand_record(recs + q * (size_t)stride, stride, row_bytes, r1.seq, r1.len, r2.seq, r2.len, a1.data(), a2.data(), &s) != SA_OK) {
-                            bad.store(1);
-                            break;
-                        }
-                        pos += format_row(b.data() + pos, L, r1, r2, a1.data(), a2.data(), s);
-                        if (schedule == SA_SCHEDULE_ADJACENT) { i++; j++; }
-                        else if (++j == n) { i++; j = i + 1; }
-                    }
-                    used[(size_t)t] = pos;
-                };
-                const double tf0 = now_s();
-                std::vector<std::thread> th;
-                for (int t = 1; t < nthreads; t++) th.emplace_back(work, t);
-                work(0);
-                for (auto& x : th) x.join();
-                t_format += now_s() - tf0;
-                if (bad.load()) { rc = SA_ERR_RECORD; }
-                if (rc == SA_OK) {
-                    // chunks are written in order: the previous writer must be done before this one starts
-                    const double tj1 = now_s();
-                    if (writer[cur_set ^ 1].joinable()) writer[cur_set ^ 1].join();
-                    t_write += now_s() - tj1;
-                    // every format slice goes to its own place in the file, all slices at once
-                    const uint64_t chunk_off = file_off;
-                    for (int t = 0; t < nthreads; t++) file_off += used[(size_t)t];
-                    writer[cur_set] = std::thread([&bufs, &used, &write_failed, &written, out_fd, nthreads, chunk_off]() {
-                        std::vector<uint64_t> at((size_t)nthreads + 1, chunk_off);
-                        for (int t = 0; t < nthreads; t++) at[(size_t)t + 1] = at[(size_t)t] + used[(size_t)t];
-                        sa_parallel_for((uint64_t)nthreads, 1, [&](uint64_t lo, uint64_t hi, unsigned) {
-                            for (uint64_t t = lo; t < hi; t++)
-                                if (!pwrite_all(out_fd, bufs[t].data(), used[t], at[t])) write_failed.store(true);
+            { std::lock_guard<std::mutex> lk(D.m); D.submit_done = true; }
+            D.cv.notify_all();
+        };
+        auto drain_loop = [&](int d) {
+            Dev& D = devs[(size_t)d];
+            sa_ctx* c = ctx[(size_t)d];
+            // host formatting: two sets of buffers, one is written to the file while the other is filled
+            std::vector<std::vector<char>> bufset[2] = {std::vector<std::vector<char>>((size_t)fthreads), std::vector<std::vector<char>>((size_t)fthreads)};
+            std::vector<size_t> usedset[2] = {std::vector<size_t>((size_t)fthreads), std::vector<size_t>((size_t)fthreads)};
+            int cur_set = 0;
+            std::thread writer;            // writes the previous chunk of this device while the next one is awaited
+            auto join_writer = [&]() {
+                if (!writer.joinable()) return;
+                const double t = now_s();
+                writer.join();
+                D.t_write += now_s() - t;
+            };
+            size_t idx = 0;
+            for (size_t k = (size_t)d; k < nchunks; k += (size_t)ndev, idx++) {
+                {
+                    std::unique_lock<std::mutex> lk(D.m);
+                    D.cv.wait(lk, [&] { return D.submitted > idx || D.submit_done || err.load() != SA_OK; });
+                    if (D.submitted <= idx) break;
+                }
+                if (err.load() != SA_OK) break;
+                const uint8_t* recs = nullptr;
+                const char* text = nullptr;
+                uint64_t first = 0, np = 0, nbytes = 0;
+                const double tw0 = now_s();
+                int r = text_mode ? sa_next_text(c, &text, &nbytes, &first, &np) : sa_next(c, &recs, &first, &np);
+                D.t_wait += now_s() - tw0;
+                if (r) { set_err(r); break; }
+                if (text_mode) {
+                    // Finished rows: the slot is free again at once (the text sits in a buffer of the context that
+                    // stays valid over the next sa_next_text); a writer thread puts the slices of the text at their
+                    // place in the file while the next submission is awaited.
+                    if ((r = sa_release(c))) { set_err(r); break; }
+                    { std::lock_guard<std::mutex> lk(D.m); D.consumed++; }
+                    D.cv.notify_all();
+                    join_writer();         // the buffer the next-but-one text will overwrite is on disk
+                    publish(k, nbytes);
+                    writer = std::thread([&, k, text, nbytes]() {
+                        uint64_t at = 0;
+                        if (!offset_of(k, at)) return;
+                        sa_parallel_for(nbytes, 1 << 22, [&](uint64_t lo, uint64_t hi, unsigned) {
+                            if (!pwrite_all(out_fd, text + lo, hi - lo, at + lo)) write_failed.store(true);
                         });
-                        written.fetch_add(at[(size_t)nthreads] - chunk_off);
+                        written.fetch_add(nbytes);
+                    });
+                    chunks_done.fetch_add(1);
+                    continue;
+                }
+                if (st->mode_write && np) {
+                    join_writer();          // one writer per device at a time: its buffer set is the other one
+                    std::vector<std::vector<char>>& bufs = bufset[cur_set];
+                    std::vector<size_t>& used = usedset[cur_set];
+                    std::atomic<int> bad(0);
+                    auto work = [&](int t) {
+                        const uint64_t lo = np * (uint64_t)t / (uint64_t)fthreads, hi = np * (uint64_t)(t + 1) / (uint64_t)fthreads;
+                        std::vector<char>& b = bufs[(size_t)t];
+                        if (b.size() < (hi - lo) * row_bound + 16) b.resize((hi - lo) * row_bound + 16);
+                        std::vector<char> a1(2 * (size_t)longest_seq + 2), a2(2 * (size_t)longest_seq + 2);
+                        size_t pos = 0;
+                        // pair (i, j) of the first record of this slice
+                        uint64_t i, j;
+                        if (schedule == SA_SCHEDULE_ADJACENT) { i = first + lo; j = i + 1; }
+                        else {
+                            i = chunks[k].r0;
+                            uint64_t ix = first + lo;
+                            while (sa_pair_index(c, schedule, i + 1) <= ix) i++;
+                            j = i + 1 + (ix - sa_pair_index(c, schedule, i));
+                        }
+                        for (uint64_t q = lo; q < hi; q++) {
+                            const Row& r1 = tab.rows[i];
+                            const Row& r2 = tab.rows[j];
+                            sa_alignment_stats s;
+                            if (sa_expand_record(recs + q * (size_t)stride, stride, row_bytes, r1.seq, r1.len, r2.seq, r2.len, a1.data(), a2.data(), &s) != SA_OK) {
+                                bad.store(1);
+                                break;
+                            }
+                            pos += format_row(b.data() + pos, L, r1, r2, a1.data(), a2.data(), s);
+                            if (schedule == SA_SCHEDULE_ADJACENT) { i++; j++; }
+                            else if (++j == n) { i++; j = i + 1; }
+                        }
+                        used[(size_t)t] = pos;
+                    };
+                    const double tf0 = now_s();
+                    std::vector<std::thread> th;
+                    for (int t = 1; t < fthreads; t++) th.emplace_back(work, t);
+                    work(0);
+                    for (auto& x : th) x.join();
+                    D.t_format += now_s() - tf0;
+                    if (bad.load()) { set_err(SA_ERR_RECORD); break; }
+                    uint64_t total_bytes = 0;
+                    for (int t = 0; t < fthreads; t++) total_bytes += used[(size_t)t];
+                    publish(k, total_bytes);
+                    // every format slice goes to its own place in the file, all slices at once
+                    writer = std::thread([&, k, total_bytes, cur_set]() {
+                        uint64_t chunk_off = 0;
+                        if (!offset_of(k, chunk_off)) return;
+                        std::vector<std::vector<char>>& wb = bufset[cur_set];
+                        std::vector<size_t>& wu = usedset[cur_set];
+                        std::vector<uint64_t> at((size_t)fthreads + 1, chunk_off);
+                        for (int t = 0; t < fthreads; t++) at[(size_t)t + 1] = at[(size_t)t] + wu[(size_t)t];
+                        sa_parallel_for((uint64_t)fthreads, 1, [&](uint64_t lo, uint64_t hi, unsigned) {
+                            for (uint64_t t = lo; t < hi; t++)
+                                if (!pwrite_all(out_fd, wb[t].data(), wu[t], at[t])) write_failed.store(true);
+                        });
+                        written.fetch_add(total_bytes);
                     });
                     cur_set ^= 1;
+                } else {
+                    publish(k, 0);
                 }
+                if ((r = sa_release(c))) { set_err(r); break; }
+                { std::lock_guard<std::mutex> lk(D.m); D.consumed++; }
+                D.cv.notify_all();
+                chunks_done.fetch_add(1);
             }
-            if (rc == SA_OK) rc = sa_release(c);
-            rep->chunks_done++;
+            join_writer();
+            // a drain thread that stops early must not leave its submit thread waiting for a free slot
+            if (err.load() != SA_OK) { { std::lock_guard<std::mutex> lk(D.m); D.consumed = D.submitted; } D.cv.notify_all(); }
+        };
+        std::vector<std::thread> workers;
+        for (int d = 0; d < ndev; d++) {
+            workers.emplace_back(submit_loop, d);
+            workers.emplace_back(drain_loop, d);
         }
-        const double tj2 = now_s();
-        if (text_writer.joinable()) text_writer.join();
-        for (auto& w : writer) if (w.joinable()) w.join();
-        t_write += now_s() - tj2;
+        for (auto& w : workers) w.join();
+        rc = err.load();
+        rep->chunks_done = chunks_done.load();
+        for (int d = 0; d < ndev; d++) {
+            const Dev& D = devs[(size_t)d];
+            t_wait += D.t_wait; t_format += D.t_format; t_write += D.t_write;
+            rep->device_submit[d] = D.t_submit; rep->device_wait[d] = D.t_wait;
+            rep->device_format[d] = D.t_format; rep->device_write[d] = D.t_write;
+        }
         rep->bytes_written += written.load();
         if (write_failed.load()) io_ok = false;
     }

@@ -16,6 +16,8 @@
 // kernel only for tables with 1 <= S' <= 24 (BLOSUM50 with gap -4: 3 .. 23).
 // The border column travels between strips as absolute 32-bit values, one per half.
 #include "sa_pair_common.h"
+
+#define SA_LONG_PAIR_PROF_STRIDE SA_PAIR_PROF_STRIDE(16)   /* 66 dwords; the LDS is sized for 68 (SA_LDS_PROF_BYTES) */
 #include "sa_traceback.h"
 
 template <int WAVES_PER_SIMD>
@@ -100,10 +102,10 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_pair_kernel(const 
                         // padding scores 1 instead of 0 (an odd column's table entry must stay positive); padded
                         // cells lie to the right of and below every cell that is read
                         const int s1 = max(P.sprime[a1 * SA_SPRIME_STRIDE + b], 1), s2 = max(P.sprime[a2 * SA_SPRIME_STRIDE + b], 1);
-                        prof[b * SA_PROF_STRIDE + SA_NB_PROF_INDEX(lane, SA_PROF_STRIDE)] = (lane & 1) ? SA_NB_TABLE_B(s1) | (SA_NB_TABLE_B(s2) << 16)
+                        prof[b * SA_LONG_PAIR_PROF_STRIDE + SA_NB_PROF_INDEX(lane, SA_LONG_PAIR_PROF_STRIDE)] = (lane & 1) ? SA_NB_TABLE_B(s1) | (SA_NB_TABLE_B(s2) << 16)
                                                                      : SA_NB_TABLE_A(s1) | (SA_NB_TABLE_A(s2) << 16);
                     }
-                    prof[20 * SA_PROF_STRIDE + SA_NB_PROF_INDEX(lane, SA_PROF_STRIDE)] = (lane & 1) ? SA_NB_TABLE_B(1) * 0x10001 : SA_NB_TABLE_A(1) * 0x10001;
+                    prof[20 * SA_LONG_PAIR_PROF_STRIDE + SA_NB_PROF_INDEX(lane, SA_LONG_PAIR_PROF_STRIDE)] = (lane & 1) ? SA_NB_TABLE_B(1) * 0x10001 : SA_NB_TABLE_A(1) * 0x10001;
                     __syncthreads();
                 }
                 uint32_t R[SA_LP];        // the DP row of the strip, updated in place
@@ -155,7 +157,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_pair_kernel(const 
                 // read): with the row under a per-lane condition the compiler keeps a second copy of the register row
                 // for the lanes that skip it.  A lane takes its scores when its last row is done.
 #define SA_LP_ROW(RR, DA, DB, LA, LB, B)                                                                                  \
-    fill_row_pair<SA_LP / 4, SA_PROF_STRIDE>(R, gend, rel(DA, DB) | SA_NB_UP_B, rel(LA, LB), prof + (B) * SA_PROF_STRIDE, e);              \
+    fill_row_pair<SA_LP / 4, SA_LONG_PAIR_PROF_STRIDE>(R, gend, rel(DA, DB) | SA_NB_UP_B, rel(LA, LB), prof + (B) * SA_LONG_PAIR_PROF_STRIDE, e);              \
     store_dirs(RR);                                                                                                        \
     if ((RR) + 1 == lenq) {                                                                                                \
         capA = (int)((pick_packed<SA_LP>(R, colA) & 0xffffu) >> SA_NB_SHIFT) + base1;                                      \

@@ -13,7 +13,8 @@ static void usage(const char* argv0) {
     fprintf(stderr,
             "usage: %s [--config user.h] [--input in.csv] [--output out.csv]\n"
             "          [--schedule adjacent|triangular] [--gap N] [--max-seq-len N]\n"
-            "          [--devices N] [--threads N] [--pairs-per-submit N] [--no-write] [--no-pairing] [--host-format]\n",
+            "          [--matrix file] [--devices N] [--threads N] [--pairs-per-submit N] [--no-write] [--no-pairing]\n"
+            "          [--host-format]\n",
             argv0);
 }
 
@@ -36,6 +37,7 @@ int main(int argc, char** argv) {
             st.schedule = !strcmp(v, "triangular") ? SA_SCHEDULE_TRIANGULAR : SA_SCHEDULE_ADJACENT;
         } else if (!strcmp(a, "--gap")) st.gap_penalty = atoi(need(a));
         else if (!strcmp(a, "--max-seq-len")) st.max_seq_len = (uint32_t)atoi(need(a));
+        else if (!strcmp(a, "--matrix")) snprintf(st.scoring_matrix_file, sizeof(st.scoring_matrix_file), "%s", need(a));
         else if (!strcmp(a, "--devices")) st.num_devices = atoi(need(a));
         else if (!strcmp(a, "--threads")) st.format_threads = atoi(need(a));
         else if (!strcmp(a, "--pairs-per-submit")) st.pairs_per_submit = strtoull(need(a), nullptr, 10);

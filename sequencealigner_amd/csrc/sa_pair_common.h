@@ -77,9 +77,16 @@
 // is written as an instruction so that it stays here: left to the compiler it moves into the next group (the
 // only place its result is used) behind a copy of the register it reads.
 typedef int sa_i32x4 __attribute__((ext_vector_type(4)));
+typedef int sa_i32x2 __attribute__((ext_vector_type(2)));
 #define SA_GROUP_PK(G)                                                                          \
     {                                                                                           \
-        const sa_i32x4 sc_ = *reinterpret_cast<const sa_i32x4*>(row_base + 4 * (G));            \
+        sa_i32x4 sc_;                                                                           \
+        {                                                                                       \
+            sa_i32x2 lo_, hi_;                                                                  \
+            asm volatile("ds_read_b64 %0, %2 offset:%3\n\tds_read_b64 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)" \
+                         : "=&v"(lo_), "=&v"(hi_) : "v"(row_lds), "n"(16 * (G)), "n"(16 * (G) + 8)); \
+            sc_.x = lo_.x; sc_.y = lo_.y; sc_.z = hi_.x; sc_.w = hi_.y;                         \
+        }                                                                                       \
         uint32_t mb0_ = B[4 * (G)] + (uint32_t)sc_.x;                                           \
         uint32_t ma1_ = B[4 * (G) + 1] + (uint32_t)sc_.y;                                       \
         SA_CELL_NB(B, 4 * (G), ma_, mb0_, e[(G) >> 1])                                          \
@@ -104,6 +111,9 @@ __device__ __forceinline__ void fill_row_pair(uint32_t (&B)[4 * NG], const int g
     uint32_t zl = left0;
     uint32_t upb = SA_NB_UP_B;
     asm volatile("" : "+v"(upb));          // one register for the whole row, not a copy per use
+    // the lane's profile row as an LDS byte address: the four entries of a group come as two 8-byte reads (rows are
+    // 2 banks apart modulo 64, see sa_device.h: 16-byte reads of rows 4 banks apart collide for residues b and b + 16)
+    const uint32_t row_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const int32_t*)row_base;
     uint32_t ma_ = diag0 + (uint32_t)row_base[PS - 1];
     SA_GROUP_PK(0) SA_GROUP_PK(1) SA_GROUP_PK(2) SA_GROUP_PK(3) SA_GROUP_PK(4) SA_GROUP_PK(5) SA_GROUP_PK(6)
     SA_GROUP_PK(7) SA_GROUP_PK(8) SA_GROUP_PK(9) SA_GROUP_PK(10) SA_GROUP_PK(11) SA_GROUP_PK(12)

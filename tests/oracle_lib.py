@@ -54,10 +54,13 @@ def align(s1, s2, gap=-4, matrix=None):
     return a1.value, a2.value, r
 
 
-def run_file(in_path, out_path, schedule, threads=1, gap=-4, max_pairs=0):
+def run_file(in_path, out_path, schedule, threads=1, gap=-4, max_pairs=0, matrix=None):
     st = RunStats()
+    mat = None
+    if matrix is not None:
+        mat = (C.c_int32 * 400)(*[int(x) for x in matrix])
     rc = oracle().sa_oracle_run_file(in_path.encode(), out_path.encode() if out_path else None, schedule, threads,
-                                     gap, None, max_pairs, C.byref(st))
+                                     gap, mat, max_pairs, C.byref(st))
     if rc != 0:
         raise RuntimeError(f"oracle run error {rc}")
     return st

@@ -420,6 +420,13 @@ def test_csv_driver_deals_chunks_to_several_contexts(tmp_path, schedule):
     rep = sa.run_csv(str(src), str(got), schedule, settings=st, pairs_per_submit=7000)
     assert rep.chunks_done >= 6
     assert got.read_bytes() == want.read_bytes()
+    # every context had its own submit and drain thread, and reported what they spent
+    assert all(rep.device_submit[k] > 0 and rep.device_wait[k] > 0 for k in range(3))
+    assert rep.device_submit[3] == 0 and abs(sum(rep.device_wait) - rep.seconds_gpu_wait) < 1e-9
+    # the same through the host formatter
+    st.device_format = 0
+    sa.run_csv(str(src), str(got), schedule, settings=st, pairs_per_submit=7000, format_threads=5)
+    assert got.read_bytes() == want.read_bytes()
 
 
 @pytest.mark.gpu
@@ -655,3 +662,82 @@ def test_random_tables_gaps_and_lengths(seed):
     assert len(adj) == n - 1
     _check_pairs(al, adj, [(k, k + 1) for k in range(n - 1)], gap=gap, matrix=matrix)
     al.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("device_format", [1, 0])
+def test_scoring_matrix_from_the_settings_surface(tmp_path, device_format):
+    """SA_SCORING_MATRIX names a file with another substitution table (asymmetric, not BLOSUM): the CSV driver on both
+    schedules, rows written on the GPU and on the host, against the checker with the same table."""
+    from test_host import _write_matrix
+    rng = random.Random(12)
+    matrix = [rng.randint(-5, 9) for _ in range(400)]
+    mfile = tmp_path / "matrix.txt"
+    _write_matrix(str(mfile), matrix)
+    seqs, labels = synth.generate(500, 2, 60, seed=13)
+    src = tmp_path / "in.csv"
+    synth.write_csv(str(src), seqs, labels)
+    for schedule in (sa.ADJACENT, sa.TRIANGULAR):
+        want, got = tmp_path / "oracle.csv", tmp_path / "gpu.csv"
+        oracle_lib.run_file(str(src), str(want), schedule, threads=8, gap=-3, matrix=matrix)
+        sa.run_csv(str(src), str(got), schedule, gap_penalty=-3, scoring_matrix_file=str(mfile).encode(),
+                   device_format=device_format)
+        assert got.read_bytes() == want.read_bytes()
+    # a BLOSUM run of the same file differs: the table did reach the kernels
+    other = tmp_path / "blosum.csv"
+    sa.run_csv(str(src), str(other), sa.ADJACENT, gap_penalty=-3)
+    oracle_lib.run_file(str(src), str(tmp_path / "oracle.csv"), sa.ADJACENT, threads=8, gap=-3, matrix=matrix)
+    assert other.read_bytes() != (tmp_path / "oracle.csv").read_bytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lo,hi", [(3, 60), (65, 300)])
+def test_cloned_context_gives_the_same_records_and_text(lo, hi):
+    """sa_clone_sequences: a second context takes sequences, schedule tables, pass-through text and layout from the
+    first by device-to-device copies; both produce the same records and the same text."""
+    rng = random.Random(31)
+    seqs = ["".join(rng.choice(ALPHABET) for _ in range(rng.randint(lo, hi))) for _ in range(300)]
+    labels = ["id%d" % k for k in range(300)]
+    a = sa.Aligner(max_seq_len=max(64, hi))
+    a.upload(seqs)
+    a.set_text_layout([_lib.TEXT_SEQ1, _lib.TEXT_SEQ2, _lib.TEXT_OTHER1, _lib.TEXT_OTHER2, _lib.TEXT_SCORE, _lib.TEXT_ALIGN])
+    a.upload_passthrough(labels)
+    a.prepare_schedule(sa.TRIANGULAR)
+    b = sa.Aligner(max_seq_len=max(64, hi))
+    b.clone_from(a)
+    assert b.rows(sa.TRIANGULAR) == 299 and b.stride == a.stride and b.row_bytes == a.row_bytes
+    assert b.cell_count(sa.TRIANGULAR, 0, 299) == a.cell_count(sa.TRIANGULAR, 0, 299)
+    assert np.array_equal(a.align(sa.TRIANGULAR, 5, 80), b.align(sa.TRIANGULAR, 5, 80))
+    assert np.array_equal(a.align(sa.ADJACENT), b.align(sa.ADJACENT))
+    assert a.align_text(sa.TRIANGULAR, 100, 110) == b.align_text(sa.TRIANGULAR, 100, 110)
+    # a clone made before the tables exist builds its own on first use
+    c = sa.Aligner(max_seq_len=max(64, hi))
+    fresh = sa.Aligner(max_seq_len=max(64, hi))
+    fresh.upload(seqs)
+    c.clone_from(fresh)
+    assert np.array_equal(c.align(sa.TRIANGULAR, 0, 40), a.align(sa.TRIANGULAR, 0, 40))
+    small = sa.Aligner(max_seq_len=2)
+    with pytest.raises(sa.SaError):
+        small.clone_from(a)
+
+
+@pytest.mark.gpu
+def test_library_names_the_kernel_it_ran():
+    seqs, _ = synth.generate(600, 6, 50, seed=5)
+    al = sa.Aligner()
+    assert al.last_kernel() == ""
+    al.upload(seqs)
+    al.align(sa.TRIANGULAR)
+    assert al.last_kernel() == "sa_peptide_pair_kernel<13, 4>"
+    al.set_pairing(False)
+    al.align(sa.TRIANGULAR)
+    assert al.last_kernel() == "sa_peptide_kernel<0, 3>"
+    al.align(sa.ADJACENT)
+    assert al.last_kernel() == "sa_peptide_kernel<1, 2>"
+    long_seqs, _ = synth.generate(80, 100, 300, seed=6)
+    bl = sa.Aligner(max_seq_len=300)
+    bl.upload(long_seqs)
+    bl.align(sa.TRIANGULAR)
+    assert bl.last_kernel() == "sa_long_pair_kernel<4>"
+    bl.align(sa.ADJACENT)
+    assert bl.last_kernel() == "sa_long_kernel<1, 2>"

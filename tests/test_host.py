@@ -325,3 +325,52 @@ def test_tiles_per_item_follow_the_size_of_the_row_range():
     assert max(int(it[2]) for it in small.tolist()) == 1          # 4.5 M pairs: 35 000 tiles for 4 000 workgroups
     al.set_tuning(tiles_per_item=4)
     assert max(int(it[2]) for it in al.work_items(sa.TRIANGULAR, 0, 2999).tolist()) == 4
+
+
+def _write_matrix(path, matrix, header=True):
+    letters = "ARNDCQEGHILKMFPSTWYV"
+    with open(path, "w") as f:
+        f.write("# substitution matrix, rows = residue of sequence 1\n")
+        if header:
+            f.write("   " + "  ".join(letters) + "\n")
+        for a in range(20):
+            row = " ".join("%3d" % matrix[a * 20 + b] for b in range(20))
+            f.write((letters[a] + " " if header else "") + row + "\n")
+
+
+def test_scoring_matrix_file_loader(tmp_path):
+    """SA_SCORING_MATRIX: 400 integers in alphabet order; comment lines, a header row of letters and a leading
+    letter per row are skipped; anything else is refused with a message."""
+    import ctypes as C
+    import random
+    lib = sa.load_library()
+    rng = random.Random(4)
+    matrix = [rng.randint(-9, 14) for _ in range(400)]
+    S = (C.c_int32 * 400)()
+    msg = C.create_string_buffer(200)
+    for header in (True, False):
+        path = tmp_path / ("m%d.txt" % header)
+        _write_matrix(str(path), matrix, header)
+        assert lib.sa_load_matrix_file(str(path).encode(), S, msg, 200) == 0, msg.value
+        assert list(S) == matrix
+    commas = tmp_path / "commas.csv"
+    commas.write_text("\n".join(",".join(str(matrix[a * 20 + b]) for b in range(20)) for a in range(20)))
+    assert lib.sa_load_matrix_file(str(commas).encode(), S, msg, 200) == 0 and list(S) == matrix
+    short = tmp_path / "short.txt"
+    short.write_text(" ".join(str(x) for x in matrix[:399]))
+    assert lib.sa_load_matrix_file(str(short).encode(), S, msg, 200) == -1 and b"399" in msg.value
+    junk = tmp_path / "junk.txt"
+    junk.write_text(" ".join(str(x) for x in matrix[:100]) + " 3.5 " + " ".join(str(x) for x in matrix[100:]))
+    assert lib.sa_load_matrix_file(str(junk).encode(), S, msg, 200) == -1 and b"3.5" in msg.value
+    assert lib.sa_load_matrix_file(str(tmp_path / "missing.txt").encode(), S, msg, 200) == -1
+    # the setting: read from a user.h-style file, checked by the validator
+    good = tmp_path / "m1.txt"
+    cfg = tmp_path / "user.h"
+    cfg.write_text('#define GAP_PENALTY -3\n#define SA_SCORING_MATRIX "%s"\n' % good)
+    st = sa.load_settings(str(cfg))
+    assert st.scoring_matrix_file.decode() == str(good) and st.gap_penalty == -3
+    rc, text = sa.validate_settings(st)
+    assert rc == 0, text
+    st.scoring_matrix_file = str(short).encode()
+    rc, text = sa.validate_settings(st)
+    assert rc != 0 and "399" in text
