@@ -8,11 +8,26 @@ in HBM before the timed region.  With N > 1 the triangular pair space is split
 into N contiguous row ranges of equal cell count, one per rank, with no
 collective on the data path (total work is fixed: strong scaling).
 
-Prints one JSON line (rank 0).
+`python bench.py --gpus N` without a torchrun environment starts the N ranks itself
+(before anything touches a GPU) and passes their output through.
+
+Rank 0 prints one JSON line.  Besides the contract's fields it carries
+  roofline      the dominant kernel against the INT32 VALU line (5 ops per DP cell), plus the
+                issue rate (VALU instructions actually issued), the LDS rate and the memory-side
+                traffic, from rocprofv3 counter passes of this command kept under profiles/
+  cpu_baseline  the reference's own multithreaded program (compiled from its sources into
+                oracle/_ref) on the mega data set, and this repository's CPU restatement on a
+                bounded sample of the bench workload, both on this box's host cores
+  extra         the same workload on the 32-bit kernel, through PCIe to pinned host memory
+                (the reference's "without write"), the 4 001 280-row data set end to end into
+                a CSV file (its "with write"), and the protein workloads
 """
 import argparse
+import hashlib
 import json
 import os
+import re
+import subprocess
 import sys
 import tempfile
 import time
@@ -20,32 +35,19 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-import sequencealigner_amd as sa  # noqa: E402
-from sequencealigner_amd import synth  # noqa: E402
-
 # INT32 VALU peak used for the roofline: 256 CUs x 64 lanes x 2.4 GHz.  Measured on
 # the device with tools/valu_peak.hip: 35-40 T lane-instructions/s for max3 / compare
 # / alignbit / packed ops, 55-64 T for plain add / sub / logic (profiles/r01_valu_issue_rates.txt).
 PEAK_TIOPS = 256 * 64 * 2.4e9 / 1e12
 OPS_PER_CELL = 5          # 3 adds + 2 max of the reference recurrence (include/seqalign.h:55-58)
-# Memory-side bytes per launch of the dominant kernel, from separate rocprofv3 --pmc passes of this
-# same command (FETCH_SIZE doubled as the gfx950 counter requires, WRITE_SIZE as read); the passes
-# and their output are kept under profiles/.  Reported as roofline.traffic when the file is there.
-PMC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")
-
-
-def measured_traffic(kernel, workload):
-    try:
-        with open(PMC_FILE) as f:
-            rec = json.load(f)
-        if rec.get("kernel") == kernel and rec.get("workload") == workload:
-            return rec.get("bytes_per_launch")
-    except (OSError, ValueError):
-        pass
-    return None
+LDS_PEAK_TBS = 150.0      # all CUs streaming ds_read_b64 / b128 at 2.4 GHz (256 B per clock and CU)
+HBM_PEAK_GBS = 8000.0
+# Per-launch counter totals of the kernels, from separate rocprofv3 --pmc passes of this same command
+# (tools/pmc_pass.sh; FETCH_SIZE doubled as gfx950 requires, WRITE_SIZE as read).  The passes' summaries
+# are kept under profiles/; this file is refreshed whenever a kernel changes.
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
+MEGA_SHA256 = "667f3524a9ba31243de55c075165b336010ffeaf76600b39540b54f5dd085f18"   # the reference's own output, 500 832 027 bytes
+MEGA_CELLS = 2214981084
 
 WORKLOADS = {
     # name: (n, lo, hi, seed, description)
@@ -57,80 +59,191 @@ WORKLOADS = {
 }
 
 
+def spawn_ranks(args):
+    """--gpus N outside a torchrun environment: start the N ranks as a fresh child job.  Nothing in this
+    process has touched a GPU yet (counting devices does not initialise one)."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} asked for, {have} visible", file=sys.stderr)
+        return 2
+    port = 29500 + os.getpid() % 2000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
+
+
+def pmc_record(kernel, workload):
+    try:
+        with open(PMC_FILE) as f:
+            return json.load(f).get(f"{kernel}|{workload}")
+    except (OSError, ValueError):
+        return None
+
+
 def shard_for_rank(al, schedule, rank, world):
     """Contiguous row range of the schedule owned by `rank`: equal cells per rank."""
     b = al.shard_rows(schedule, world)
     return b[rank], b[rank + 1]
 
 
-def reduce_max(x):
-    if dist.is_available() and dist.is_initialized():
-        t = torch.tensor([x], dtype=torch.float64)
-        if dist.get_backend() == "nccl":
-            t = t.cuda()
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
-    return float(x)
+def scratch_dir():
+    return "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
 
 
-def reduce_sum(t):
-    if dist.is_available() and dist.is_initialized():
-        if dist.get_backend() == "nccl":
-            t = t.cuda()
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        return t.cpu()
-    return t
+def host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return os.cpu_count() or 1
 
 
-def barrier_sync():
-    if dist.is_available() and dist.is_initialized():
-        dist.barrier()
-    if torch.cuda.is_available():
-        torch.cuda.synchronize()
-
-
-def cpu_baseline(seqs, labels, sample_n):
-    """The CPU restatement (oracle/nw_oracle.c, the reference's multithreaded path
-    re-stated) timed on the host cores of this box on a bounded sample of the same
-    workload: the first `sample_n` sequences, all-vs-all, without writing."""
+def cpu_baseline(sa, synth, seqs, labels, sample_n, mega_path):
+    """Host-core baselines of this box, outside the timed region.
+    kind "reference": oracle/_ref/ref_main_mt_nowrite, the reference's src/main.c + include/thread.h pool compiled
+    from its own sources with its release flags, MODE_MULTITHREAD 1, MODE_WRITE 0, on the mega data set (its own
+    headline case, README.md:165-170); it picks min(online CPUs, 16) threads itself (include/thread.h:57-66).
+    "port": oracle/nw_oracle.c (this repository's restatement) on the first `sample_n` sequences of the bench
+    workload, all-vs-all, no write, at min(cores, 16) threads and at every core this process may use."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
 
-    threads = min(16, os.cpu_count() or 1)
-    with tempfile.TemporaryDirectory() as d:
+    cores = host_cores()
+    out = {}
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "ref_main_mt_nowrite")
+    if mega_path and os.path.exists(ref_bin):
+        best = None
+        for _ in range(2):
+            env = dict(os.environ, SA_REF_INPUT=mega_path, SA_REF_OUTPUT=os.devnull)
+            p = subprocess.run([ref_bin], env=env, capture_output=True, text=True, timeout=300)
+            m = re.search(r"Alignment time: ([0-9.]+) seconds", p.stdout)
+            if p.returncode == 0 and m:
+                t = float(m.group(1))
+                best = t if best is None else min(best, t)
+        if best:
+            out = {"value": round(MEGA_CELLS / best / 1e9, 3), "unit": "GCUPS", "cores": min(cores, 16), "kind": "reference",
+                   "pairs_per_s": round(4001279 / best, 1), "seconds": round(best, 4),
+                   "sample": "the reference's multithreaded program (src/main.c, include/thread.h pool) built from its sources, "
+                             "MODE_WRITE 0, on the 4 001 280-row mega data set (adjacent pairs, 4 001 279 pairs, "
+                             f"{MEGA_CELLS} cells), best of 2 runs, min(online CPUs, 16) threads"}
+    with tempfile.TemporaryDirectory(dir=scratch_dir()) as d:
         path = os.path.join(d, "sample.csv")
         synth.write_csv(path, seqs[:sample_n], labels[:sample_n])
-        st = oracle_lib.run_file(path, None, 1, threads=threads)
-    return {
-        "value": round(st.cells / st.seconds / 1e9, 3),
-        "unit": "GCUPS",
-        "pairs_per_s": round(st.pairs / st.seconds, 1),
-        "cores": threads,
-        "kind": "port",
-        "seconds": round(st.seconds, 3),
-        "sample": f"first {sample_n} of the {len(seqs)} sequences, all-vs-all ({st.pairs} pairs, {st.cells} cells), "
-                  f"score + traceback, no CSV write, {threads} threads",
-    }
+        ports = []
+        for threads in sorted({min(cores, 16), min(cores, 64)}):
+            st = oracle_lib.run_file(path, None, 1, threads=threads)
+            ports.append({"value": round(st.cells / st.seconds / 1e9, 3), "unit": "GCUPS", "cores": threads, "kind": "port",
+                          "pairs_per_s": round(st.pairs / st.seconds, 1), "seconds": round(st.seconds, 3),
+                          "sample": f"first {sample_n} of the {len(seqs)} sequences, all-vs-all ({st.pairs} pairs, {st.cells} cells), "
+                                    f"score + traceback, no CSV write, {threads} threads"})
+    if out:
+        out["port"] = ports
+    else:
+        out = dict(ports[0])
+        out["port"] = ports[1:]
+    out["host_cores_available"] = cores
+    return out
 
 
-def side_measurement(name, device):
-    """A second workload measured after the timed region (not part of `value`): the
-    long-sequence kernel on a prefix of the protein set of BASELINE.json configs[4]."""
+def resident_measurement(sa, synth, name, device, launches=2, pairing=True):
+    """A workload measured with the records left in HBM (not part of `value`)."""
     n, lo, hi, seed, desc = WORKLOADS[name]
     seqs, _ = synth.generate(n, lo, hi, seed)
-    al = sa.Aligner(device=device, max_seq_len=hi)
+    al = sa.Aligner(device=device, max_seq_len=max(64, hi))
+    al.set_pairing(pairing)
     al.upload(seqs)
     rows = al.rows(sa.TRIANGULAR)
     cells = al.cell_count(sa.TRIANGULAR, 0, rows)
     pairs = al.pair_count(sa.TRIANGULAR, 0, rows)
     al.prepare_resident(sa.TRIANGULAR, 0, rows)
     al.run_resident()
-    ms = [al.run_resident() for _ in range(2)]
+    ms = [al.run_resident() for _ in range(launches)]
+    kernel = al.last_kernel()
     al.close()
     k_ms = sum(ms) / len(ms)
-    return {"workload": desc, "pairs": pairs, "cells": cells, "kernel_ms": round(k_ms, 3),
-            "gcups": round(cells / k_ms / 1e6, 1), "pairs_per_s": round(pairs / k_ms * 1e3, 1),
-            "roofline_frac": round(cells * OPS_PER_CELL / (k_ms * 1e-3) / 1e12 / PEAK_TIOPS, 4)}
+    out = {"workload": desc, "kernel": kernel, "pairs": pairs, "cells": cells, "kernel_ms": round(k_ms, 3),
+           "gcups": round(cells / k_ms / 1e6, 1), "pairs_per_s": round(pairs / k_ms * 1e3, 1),
+           "roofline_frac": round(cells * OPS_PER_CELL / (k_ms * 1e-3) / 1e12 / PEAK_TIOPS, 4)}
+    rec = pmc_record(kernel, name)
+    if rec:
+        out["counters"] = counter_rates(rec, k_ms)
+    return out
+
+
+def counter_rates(rec, k_ms):
+    """Rates from the per-launch counter totals of profiles/ and the kernel time measured in this run."""
+    sec = k_ms * 1e-3
+    out = {"source": rec.get("source")}
+    if rec.get("valu_wave_insts"):
+        lane = rec["valu_wave_insts"] * 64
+        out["issue"] = {"lane_insts_per_launch": lane, "achieved": round(lane / sec / 1e12, 2), "peak": round(PEAK_TIOPS, 2),
+                        "unit": "T lane-instr/s", "frac": round(lane / sec / 1e12 / PEAK_TIOPS, 4)}
+    if rec.get("lds_bytes"):
+        out["lds"] = {"bytes_per_launch": rec["lds_bytes"], "achieved": round(rec["lds_bytes"] / sec / 1e12, 2),
+                      "peak": LDS_PEAK_TBS, "unit": "TB/s", "frac": round(rec["lds_bytes"] / sec / 1e12 / LDS_PEAK_TBS, 4),
+                      "bank_conflict_share": rec.get("lds_bank_conflict_share")}
+    if rec.get("fetch_bytes") is not None and rec.get("write_bytes") is not None:
+        t = rec["fetch_bytes"] + rec["write_bytes"]
+        out["memory_side"] = {"bytes_per_launch": t, "achieved": round(t / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(t / sec / 1e9 / HBM_PEAK_GBS, 4)}
+    return out
+
+
+def d2h_measurement(sa, csv_path, cells):
+    """The bench workload with every record copied to pinned host memory (sa_submit / sa_next, two submissions in
+    flight, nothing formatted or written): the reference's "without write" mode (MODE_WRITE 0, src/main.c:111-116)."""
+    rep = sa.run_csv(csv_path, None, sa.TRIANGULAR)
+    return {"what": "CSV ingest + upload + kernels + every record over PCIe to pinned host memory, no formatting, no write",
+            "seconds": round(rep.seconds, 4), "gcups": round(cells / rep.seconds / 1e9, 1),
+            "pairs_per_s": round(rep.pairs / rep.seconds, 1),
+            "record_gb_per_s": round(rep.pairs * 64 / rep.seconds / 1e9, 2),
+            "seconds_ingest": round(rep.seconds_ingest, 4), "seconds_upload": round(rep.seconds_upload, 4),
+            "seconds_gpu_wait": round(rep.seconds_gpu_wait, 4)}
+
+
+def sha256_file(path):
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        while True:
+            b = f.read(1 << 24)
+            if not b:
+                break
+            h.update(b)
+    return h.hexdigest()
+
+
+def e2e_mega(sa, mega_path, out_dir, device):
+    """BASELINE.json configs[3]: the 4 001 280-row data set, adjacent pairs, CSV in -> CSV out ("with write",
+    README.md:165-170), output checked against the sha256 of the reference's own output.  One context, then three
+    contexts on this one card (each with its own submit and drain thread), to show what the host path costs."""
+    out = {"what": "mega data set (4 001 279 adjacent pairs) CSV in -> 500 832 027-byte CSV out, set-up excluded as in the "
+                   "reference's timing (README.md:178)"}
+    for ndev in (1, 3):
+        st = sa.default_settings()
+        st.num_devices = ndev
+        for k in range(ndev):
+            st.devices[k] = device
+        dst = os.path.join(out_dir, f"mega_out_{ndev}.csv")
+        best = None
+        for _ in range(2):
+            rep = sa.run_csv(mega_path, dst, sa.ADJACENT, settings=st)
+            if best is None or rep.seconds < best.seconds:
+                best = rep
+        ok = sha256_file(dst) == MEGA_SHA256
+        os.unlink(dst)
+        out[f"contexts_{ndev}"] = {
+            "seconds": round(best.seconds, 4), "pairs_per_s": round(best.pairs / best.seconds, 1),
+            "gcups": round(best.cells / best.seconds / 1e9, 2), "bytes_written": best.bytes_written, "sha256_ok": ok,
+            "seconds_ingest": round(best.seconds_ingest, 4), "seconds_upload": round(best.seconds_upload, 4),
+            "device_wait": [round(best.device_wait[k], 4) for k in range(ndev)],
+            "device_submit": [round(best.device_submit[k], 4) for k in range(ndev)],
+            "device_write": [round(best.device_write[k], 4) for k in range(ndev)]}
+    st = sa.default_settings()
+    st.devices[0] = device
+    rep = min((sa.run_csv(mega_path, None, sa.ADJACENT, settings=st) for _ in range(2)), key=lambda r: r.seconds)
+    out["without_write"] = {"seconds": round(rep.seconds, 4), "pairs_per_s": round(rep.pairs / rep.seconds, 1),
+                            "gcups": round(rep.cells / rep.seconds / 1e9, 2)}
+    return out
 
 
 def main():
@@ -139,18 +252,35 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="peptides50k", choices=sorted(WORKLOADS))
-    ap.add_argument("--no-extra", action="store_true", help="skip the protein side measurement")
-    ap.add_argument("--cpu-sample", type=int, default=20000, help="sequences in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the side measurements (32-bit kernel, PCIe, CSV end to end, proteins)")
+    ap.add_argument("--cpu-sample", type=int, default=8000, help="sequences in the CPU restatement's sample (0 = no CPU baseline)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+
+    import torch
+    import torch.distributed as dist
+
+    import sequencealigner_amd as sa
+    from sequencealigner_amd import synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+        sys.exit(2)
     if world > 1:
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl")
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+
+    def barrier_sync():
+        if world > 1:
+            dist.barrier()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
 
     n, lo, hi, seed, desc = WORKLOADS[args.workload]
     seqs, labels = synth.generate(n, lo, hi, seed)
@@ -167,20 +297,32 @@ def main():
     t0 = time.perf_counter()
     kernel_ms = []
     for _ in range(args.steps):
-        kernel_ms.append(al.run_resident())     # launches on the library's stream and waits for it
+        kernel_ms.append(al.run_resident())     # launches on the library's stream and waits for it (HIP events around the kernel)
     barrier_sync()
-    elapsed = reduce_max(time.perf_counter() - t0)
-    totals = reduce_sum(torch.tensor([float(my_pairs), float(my_cells)], dtype=torch.float64))
-    total_pairs, total_cells = float(totals[0]), float(totals[1])
+    elapsed = time.perf_counter() - t0
+    k_ms = sum(kernel_ms) / max(1, len(kernel_ms))
+    kernel = al.last_kernel()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tot = torch.tensor([float(my_pairs), float(my_cells)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        total_pairs, total_cells = float(tot[0]), float(tot[1])
+        per = torch.zeros(world, dtype=torch.float64, device="cuda")
+        per[rank] = k_ms
+        dist.all_reduce(per, op=dist.ReduceOp.SUM)
+        per_rank_ms = [round(float(x), 3) for x in per.cpu()]
+    else:
+        total_pairs, total_cells = float(my_pairs), float(my_cells)
+        per_rank_ms = [round(k_ms, 3)]
 
     if rank == 0:
-        k_ms = sum(kernel_ms) / max(1, len(kernel_ms))
-        if hi > 64:
-            kernel = "sa_long_pair_kernel<4>"
-        else:
-            kernel = "sa_peptide_pair_kernel<13, 4>" if hi <= 52 else "sa_peptide_pair_kernel<16, 4>"
         achieved = my_cells * OPS_PER_CELL / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
-        traffic = measured_traffic(kernel, args.workload) if world == 1 and k_ms > 0 else None
+        rec = pmc_record(kernel, args.workload) if world == 1 and k_ms > 0 else None
+        rates = counter_rates(rec, k_ms) if rec else {}
+        mem = rates.get("memory_side")
+        packed = "pair" in kernel
         out = {
             "metric": "GCUPS, all-vs-all Needleman-Wunsch score+traceback (aligned pairs/s alongside)",
             "value": round(total_cells * args.steps / elapsed / 1e9, 2),
@@ -190,10 +332,11 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "kernel_ms_per_rank": per_rank_ms,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "int16",
+            "dtype": "int16" if packed else "int32",
             "data": "synthetic",
             "config": {
                 "workload": desc,
@@ -209,29 +352,54 @@ def main():
                 "peak": round(PEAK_TIOPS, 2),
                 "unit": "TIOP/s",
                 "frac": round(achieved / PEAK_TIOPS, 4),
-                "traffic": traffic,
-                "memory_side": None if traffic is None else {
-                    "achieved": round(traffic / (k_ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
-                    "frac": round(traffic / (k_ms * 1e-3) / 8e12, 4)},
+                "traffic": mem["bytes_per_launch"] if mem else None,
+                "issue_frac": rates.get("issue", {}).get("frac"),
+                "issue": rates.get("issue"),
+                "lds": rates.get("lds"),
+                "memory_side": mem,
+                "counters_from": rates.get("source"),
                 "kernel": kernel,
                 "kernel_ms": round(k_ms, 3),
                 "cells_per_launch": int(my_cells),
                 "ops_per_cell": OPS_PER_CELL,
-                "note": "INT32 VALU issue roofline: algorithmic ops = 5 per DP cell (3 adds + 2 max of the reference "
-                        "recurrence); the kernels pack two cells per lane (exact 16-bit arithmetic, 3.9 instructions "
-                        "issued per cell all told) and are still priced against the INT32 line, so frac can pass 1; "
-                        "traffic = memory-side bytes per launch from rocprofv3 PMC passes (profiles/), null when not "
-                        "measured; memory_side prices that traffic (direction rows written by the fill and read back "
-                        "by the traceback, plus the records) against the 8 TB/s HBM line",
+                "note": "frac prices the reference recurrence's 5 integer ops per DP cell (3 adds + 2 max) against the INT32 VALU line "
+                        "(256 CUs x 64 lanes x 2.4 GHz); the packed kernels hold two 16-bit cells per lane (exact), so frac can pass 1 "
+                        "-- issue_frac is the measure of how close the kernel sits to the hardware: VALU lane-instructions actually "
+                        "issued per second over the same line.  kernel_ms is measured live (HIP events on the launch stream); the "
+                        "instruction, LDS and memory-side byte counts per launch are constants of the kernel and workload taken from "
+                        "rocprofv3 counter passes of this command (file named in counters_from, null when there is none for this "
+                        "kernel); memory_side = L2-fabric bytes (direction rows written by the fill and read back by the traceback, "
+                        "plus the records; Infinity-Cache hits included) against the 8 TB/s HBM line",
             },
         }
-        if world == 1 and args.cpu_sample > 0:
-            out["cpu_baseline"] = cpu_baseline(seqs, labels, min(args.cpu_sample, n) if hi <= 64 else min(400, n))
-        if world == 1 and args.workload == "peptides50k" and not args.no_extra:
-            out["extra"] = {"proteins2k": side_measurement("proteins2k", local_rank)}
+        if world == 1 and not args.no_extra:
+            extra = {}
+            tmp = tempfile.TemporaryDirectory(dir=scratch_dir())
+            mega_path = None
+            try:
+                if args.workload == "peptides50k":
+                    al.close()
+                    extra["int32_kernel"] = resident_measurement(sa, synth, args.workload, local_rank, pairing=False)
+                    csv_path = os.path.join(tmp.name, "peptides50k.csv")
+                    synth.write_csv(csv_path, seqs, labels)
+                    extra["d2h"] = d2h_measurement(sa, csv_path, int(total_cells))
+                    mega_path = os.path.join(tmp.name, "mega.csv")
+                    synth.make_mega(os.path.join(ROOT, "tests", "golden", "avpdb.csv"), mega_path)
+                    extra["e2e_mega"] = e2e_mega(sa, mega_path, tmp.name, local_rank)
+                    extra["proteins2k"] = resident_measurement(sa, synth, "proteins2k", local_rank)
+                    extra["proteins10k"] = resident_measurement(sa, synth, "proteins10k", local_rank, launches=1)
+                out["extra"] = extra
+                if args.cpu_sample > 0:
+                    out["cpu_baseline"] = cpu_baseline(sa, synth, seqs, labels, min(args.cpu_sample, n) if hi <= 64 else min(300, n),
+                                                       mega_path)
+            finally:
+                tmp.cleanup()
+        elif world == 1 and args.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(sa, synth, seqs, labels, min(args.cpu_sample, n) if hi <= 64 else min(300, n), None)
         print(json.dumps(out), flush=True)
     al.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

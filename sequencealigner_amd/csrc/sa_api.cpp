@@ -147,6 +147,7 @@ struct sa_ctx {
     PinBuf text_ring[2];               // finished text goes to these in turn (valid until the next-but-one sa_next_text)
     int text_ring_pos = 0;
     uint32_t spill_grid = 0;
+    uint64_t spill_budget = 96ull << 30;   // bytes of direction scratch a launch of the long kernels may use (see launch_work)
     Work slots[2];
     std::mutex slot_mu;                // head / tail / inflight: one submitting and one consuming thread may overlap
     int head = 0, tail = 0, inflight = 0;
@@ -348,10 +349,13 @@ int build_items(sa_ctx* c, int schedule, uint64_t r0, uint64_t r1, std::vector<S
     return SA_OK;
 }
 
+// long sequences: direction rows per strip, sized by the longest sequence uploaded (rows are walked eight at a time)
+uint32_t long_dir_rows(const sa_ctx* c) { return (c->max_seq + 7u) & ~7u; }
+
 // global scratch of one workgroup: direction rows (and, for long sequences, the strip border columns)
 size_t spill_bytes_per_wg(const sa_ctx* c) {
     if (!is_long(c)) return (size_t)2 * SA_LP * 1024;      // two sets of direction rows for the paired kernel
-    return (size_t)2 * (c->lslot / 64) * c->lslot * 1024;       // strips x rows x 1 KiB, for each half of the paired kernel
+    return (size_t)2 * (c->lslot / 64) * long_dir_rows(c) * 1024;   // strips x rows x 1 KiB, for each half of the paired kernel
 }
 
 // 4-column register groups of the paired peptide kernel's row: 13 (52 columns) when no sequence is longer
@@ -362,7 +366,7 @@ uint32_t grid_for(const sa_ctx* c) {
         // 32-bit cells: two waves per SIMD (a third one spills registers inside the row loop: measured 1.8 vs
         // 3.0 TCUPS).  Packed cells keep one register row and run four, as far as the LDS copies of the two first
         // sequences allow.  The direction area of a workgroup is large, keep the total under 96 GiB of the 288.
-        const uint64_t budget = 96ull << 30;
+        const uint64_t budget = c->spill_budget;
         uint64_t per_cu = 8;
         if (uses_pairs(c)) per_cu = std::min<uint64_t>(16, (160u * 1024u) / (SA_LDS_PROF_BYTES + 64 + 2 * c->lslot));
         uint64_t g = std::min<uint64_t>((uint64_t)c->ncu * per_cu, budget / spill_bytes_per_wg(c));
@@ -389,6 +393,17 @@ int ensure_spill(sa_ctx* c, uint32_t grid) {
 // queue the kernels of one row range on the compute stream
 int launch_work(sa_ctx* c, Work& w, bool timed) {
     if (w.npairs == 0 || w.nitems == 0) return SA_OK;
+    if (is_long(c) && c->spill_grid == 0) {
+        // First launch after an upload: the records of this row range are allocated by now, so what is free tells how
+        // many workgroups' direction areas fit.  A full grid (16 workgroups per CU) of 1000-residue proteins takes
+        // 125 GiB; with less the launch runs fewer waves per SIMD.  16 GiB stay free for the second slot's records.
+        size_t free_b = 0, total_b = 0;
+        SA_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        // Three quarters of what is free at most (other contexts may share the card) and never the last 16 GiB.
+        const uint64_t margin = 16ull << 30;
+        const uint64_t room = free_b > margin ? free_b - margin : 0;
+        c->spill_budget = std::max<uint64_t>(std::min<uint64_t>(room, (uint64_t)free_b / 4 * 3), 1ull << 30);
+    }
     const uint32_t grid = grid_for(c);
     int rc = ensure_spill(c, grid);
     if (rc) return rc;
@@ -413,7 +428,7 @@ int launch_work(sa_ctx* c, Work& w, bool timed) {
     P.stride = c->stride;
     P.out_base_pair = w.first_pair;
     P.spill = (uint32_t*)c->d_spill.p;
-    P.spill_rows = 2 * SA_LP;
+    P.spill_rows = is_long(c) ? long_dir_rows(c) : 2 * SA_LP;
     P.nseq = (uint32_t)c->nseq;
     P.gap = c->gap;
     if (c->phase_timers) {
@@ -651,7 +666,7 @@ int sa_upload(sa_ctx* c, const uint8_t* codes, const uint64_t* offs, const uint3
     c->max_seq = lmax;
     const bool lng = lmax > SA_LP;
     const uint32_t lslot = lng ? (lmax + 63u) / 64u * 64u : SA_LP;
-    if (lslot != c->lslot) c->spill_grid = 0;     // scratch areas are sized by the slot
+    c->spill_grid = 0;                            // scratch areas are sized by the slot and the longest sequence
     c->lslot = lslot;
     c->row_bytes = lng ? 2 : 1;
     c->stride = lng ? (SA_LONG_HEADER_BYTES + 2 * lmax + 15u) & ~15u : (SA_REC_HEADER_BYTES + lmax + 15u) & ~15u;
@@ -761,7 +776,7 @@ int sa_clone_sequences(sa_ctx* dst, sa_ctx* src) {
     if (src->nseq == 0 || dst->inflight || src->max_seq > dst->max_len) return SA_ERR_STATE;
     if ((dst->device == SA_DEVICE_NONE) != (src->device == SA_DEVICE_NONE)) return SA_ERR_ARG;
     dst->nseq = src->nseq; dst->min_seq = src->min_seq; dst->max_seq = src->max_seq;
-    if (dst->lslot != src->lslot) dst->spill_grid = 0;
+    dst->spill_grid = 0;
     dst->lslot = src->lslot; dst->row_bytes = src->row_bytes; dst->stride = src->stride;
     dst->len = src->len; dst->len_suffix = src->len_suffix; dst->slots_host = src->slots_host;
     dst->resident_ready = false;

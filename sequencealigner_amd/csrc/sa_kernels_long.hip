@@ -27,7 +27,9 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_kernel(const SaPep
     const int lane = threadIdx.x;
     const uint32_t rows_cap = P.lslot;
     const uint32_t strips_cap = P.lslot >> 6;
-    uint32_t* const dirs = P.spill + (size_t)blockIdx.x * strips_cap * rows_cap * 256;
+    // direction rows: as many per strip as the longest uploaded sequence needs (a multiple of 8), not the slot size
+    const uint32_t dir_rows = P.spill_rows;
+    uint32_t* const dirs = P.spill + (size_t)blockIdx.x * strips_cap * dir_rows * 256;
     int32_t* const bcol = P.bcol + (size_t)blockIdx.x * 2 * rows_cap * 64;
     // optional phase timers: 0 fetch, 2 operands, 3 fill, 4 traceback + record
     const bool timed = P.phase_cycles != nullptr;
@@ -154,7 +156,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_kernel(const SaPep
                 // border column: four rows per lane and 16 bytes, [strip parity][row / 4][lane][row % 4]
                 const int4* bin = reinterpret_cast<const int4*>(bcol + (size_t)(s & 1) * rows_cap * 64) + lane;
                 int4* bout = reinterpret_cast<int4*>(bcol + (size_t)((s + 1) & 1) * rows_cap * 64) + lane;
-                uint32_t* drow = dirs + ((size_t)s * rows_cap * 64 + lane) * 4;
+                uint32_t* drow = dirs + ((size_t)s * dir_rows * 64 + lane) * 4;
                 const bool first_strip = s == 0, more_strips = s + 1 < nstrips;
                 // the last dword a row writes took 4*gend - 16*(wl) cells: its first column is moved down to bit 0
                 const int wl = (gend - 1) >> 2;
@@ -235,7 +237,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_kernel(const SaPep
             uint8_t* rec = out_row + (size_t)rel * P.stride;
             int j = lenp, matches = 0, gaps = 0;
             auto load_tags = [&](int sj, int r) -> uint4 {
-                return *reinterpret_cast<const uint4*>(dirs + (((size_t)sj * rows_cap + min(r, last_row)) * 64 + lane) * 4);
+                return *reinterpret_cast<const uint4*>(dirs + (((size_t)sj * dir_rows + min(r, (int)dir_rows - 1)) * 64 + lane) * 4);
             };
             constexpr bool AHEAD = MODE == SA_MODE_TRI;
             uint4 ring[AHEAD ? 8 : 1];

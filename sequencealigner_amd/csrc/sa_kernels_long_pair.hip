@@ -28,7 +28,9 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_pair_kernel(const 
     const int lane = threadIdx.x;
     const uint32_t rows_cap = P.lslot;
     const uint32_t strips_cap = P.lslot >> 6;
-    const size_t half_dirs = (size_t)strips_cap * rows_cap * 256;              // dwords of direction rows per half
+    // direction rows: as many per strip as the longest uploaded sequence needs (a multiple of 8), not the slot size
+    const uint32_t dir_rows = P.spill_rows;
+    const size_t half_dirs = (size_t)strips_cap * dir_rows * 256;              // dwords of direction rows per half
     uint32_t* const dirs = P.spill + (size_t)blockIdx.x * 2 * half_dirs;
     const size_t half_bcol = (size_t)2 * rows_cap * 64;                        // ints of border column per half
     int32_t* const bcol = P.bcol + (size_t)blockIdx.x * 2 * half_bcol;
@@ -122,7 +124,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_pair_kernel(const 
                 const int4* binB = reinterpret_cast<const int4*>(bcol + half_bcol + (size_t)(s & 1) * rows_cap * 64) + lane;
                 int4* boutA = reinterpret_cast<int4*>(bcol + (size_t)((s + 1) & 1) * rows_cap * 64) + lane;
                 int4* boutB = reinterpret_cast<int4*>(bcol + half_bcol + (size_t)((s + 1) & 1) * rows_cap * 64) + lane;
-                uint32_t* drowA = dirs + ((size_t)s * rows_cap * 64 + lane) * 4;
+                uint32_t* drowA = dirs + ((size_t)s * dir_rows * 64 + lane) * 4;
                 uint32_t* drowB = drowA + half_dirs;
                 const bool first_strip = s == 0, more_strips = s + 1 < nstrips;
 
@@ -218,7 +220,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_pair_kernel(const 
                 uint8_t* rec = (half ? out_row2 : out_row1) + (size_t)(fiq - (half ? p2 : p1) - 1) * P.stride;
                 int j = lenp, matches = 0, gaps = 0;
                 auto load_tags = [&](int sj, int r) -> uint4 {
-                    return *reinterpret_cast<const uint4*>(hd + (((size_t)sj * rows_cap + min(r, last_row)) * 64 + lane) * 4);
+                    return *reinterpret_cast<const uint4*>(hd + (((size_t)sj * dir_rows + min(r, (int)dir_rows - 1)) * 64 + lane) * 4);
                 };
                 uint4 ring[8];
                 int ring_s[8];
