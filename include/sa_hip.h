@@ -149,6 +149,10 @@ int sa_next_text(sa_ctx* ctx, const char** text, uint64_t* nbytes, uint64_t* fir
 int sa_prepare_resident(sa_ctx* ctx, int schedule, uint64_t row_begin, uint64_t row_end);
 int sa_run_resident(sa_ctx* ctx, float* kernel_ms);
 int sa_fetch_resident(sa_ctx* ctx, uint64_t first, uint64_t n, uint8_t* dst);
+/* 128-bit digest of records [first, first+n) of the resident range, computed on the device (position-dependent hash
+ * of every 16 bytes, summed): equal for two contexts exactly when their records are the same bytes in the same
+ * places, up to hash collisions.  For comparing kernels over ranges too large to copy out. */
+int sa_digest_resident(sa_ctx* ctx, uint64_t first, uint64_t n, uint64_t digest[2]);
 /* tuning knobs of the peptide kernel: 64-pair tiles per work item, workgroups (waves)
  * per CU in a launch; 0 keeps the current value.  Until they are set the library takes 1 .. 16
  * tiles per item from the size of the row range (at least 32 items per workgroup) and launches

@@ -128,6 +128,7 @@ SIGNATURES = {
     "sa_prepare_resident": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64]),
     "sa_run_resident": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "sa_fetch_resident": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, _u8p]),
+    "sa_digest_resident": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
     "sa_set_tuning": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     "sa_last_kernel": (C.c_char_p, [C.c_void_p]),
     "sa_set_pairing": (C.c_int, [C.c_void_p, C.c_int]),
@@ -389,6 +390,12 @@ class Aligner:
         out = np.zeros((n, self.stride), dtype=np.uint8)
         _check(self._lib.sa_fetch_resident(self._ctx, first, n, out.ctypes.data_as(_u8p)))
         return out
+
+    def digest_resident(self, first, n):
+        """128-bit digest (two uint64) of records [first, first+n) of the resident range, computed on the device."""
+        d = (C.c_uint64 * 2)()
+        _check(self._lib.sa_digest_resident(self._ctx, first, n, d))
+        return (d[0], d[1])
 
     def last_kernel(self):
         """Name of the fill + traceback kernel the most recent launch ran."""

@@ -22,6 +22,7 @@ extern "C" void sa_launch_peptide(int mode, int waves_per_simd, const SaPepParam
                                   unsigned lds_bytes, hipStream_t stream);
 extern "C" void sa_launch_pack_slots(const uint8_t* codes, const uint64_t* offs, const uint32_t* lens, uint64_t nseq,
                                      uint64_t nslots, uint32_t lslot, uint8_t* slots, uint16_t* len16, hipStream_t stream);
+extern "C" void sa_launch_digest(const void* records, uint64_t bytes, unsigned long long* acc, hipStream_t stream);
 extern "C" void sa_launch_peptide_pair(int ng, const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream);
 extern "C" size_t sa_format_scan_bytes(uint64_t n);
 extern "C" hipError_t sa_launch_format(const SaFormatParams* F, void* scan_tmp, size_t scan_bytes, hipStream_t stream);
@@ -1046,6 +1047,24 @@ int sa_fetch_resident(sa_ctx* c, uint64_t first, uint64_t n, uint8_t* dst) {
     if (n)
         SA_HIP_TRY(hipMemcpy(dst, (const uint8_t*)c->resident.out.p + first * c->stride, n * (size_t)c->stride,
                              hipMemcpyDeviceToHost));
+    return SA_OK;
+}
+
+int sa_digest_resident(sa_ctx* c, uint64_t first, uint64_t n, uint64_t digest[2]) {
+    if (!c || !digest) return SA_ERR_ARG;
+    if (!c->resident_ready) return SA_ERR_STATE;
+    if (first + n > c->resident.npairs) return SA_ERR_ARG;
+    SA_HIP_TRY(hipSetDevice(c->device));
+    digest[0] = digest[1] = 0;
+    if (n == 0) return SA_OK;
+    int rc = c->resident.counter.reserve(256);      // bytes 64..79 of the queue-head buffer take the two sums
+    if (rc) return rc;
+    unsigned long long* acc = (unsigned long long*)((uint8_t*)c->resident.counter.p + 64);
+    SA_HIP_TRY(hipMemsetAsync(acc, 0, 16, c->compute));
+    sa_launch_digest((const uint8_t*)c->resident.out.p + first * c->stride, n * (uint64_t)c->stride, acc, c->compute);
+    SA_HIP_TRY(hipGetLastError());
+    SA_HIP_TRY(hipMemcpyAsync(digest, acc, 16, hipMemcpyDeviceToHost, c->compute));
+    SA_HIP_TRY(hipStreamSynchronize(c->compute));
     return SA_OK;
 }
 

@@ -34,6 +34,8 @@
 // second sequences: 64 consecutive entries of p's valid list (bucket order).
 // ADJACENT mode: lane l aligns file rows (k+l, k+l+1); scores are looked up in
 // an LDS copy of S'.
+#include <algorithm>
+
 #include "sa_kernel_common.h"
 
 #include "sa_traceback.h"
@@ -325,6 +327,42 @@ __global__ __launch_bounds__(256) void sa_pack_slots_kernel(const uint8_t* __res
         w[k] = v;
     }
     *(uint4*)(slots + s * lslot + ch * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// Order-independent digest of a range of records: every 16-byte piece is hashed together with its position, the
+// hashes are summed (two sums with different mixing), so two buffers have equal digests when -- up to the odds of a
+// 128-bit collision -- they hold the same bytes at the same places.  For comparing the results of two kernels
+// over ranges too large to copy to the host.
+__device__ __forceinline__ unsigned long long sa_mix64(unsigned long long z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(256) void sa_digest_kernel(const uint4* __restrict__ pieces, unsigned long long npieces,
+                                                        unsigned long long* __restrict__ acc) {
+    unsigned long long s0 = 0, s1 = 0;
+    for (unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; k < npieces;
+         k += (unsigned long long)gridDim.x * blockDim.x) {
+        const uint4 v = pieces[k];
+        const unsigned long long a = ((unsigned long long)v.y << 32) | v.x, b = ((unsigned long long)v.w << 32) | v.z;
+        const unsigned long long h = sa_mix64(a + 0x9E3779B97F4A7C15ull * (k + 1)) ^ sa_mix64(b ^ (k * 0xD6E8FEB86659FD93ull + 1));
+        s0 += h;
+        s1 += sa_mix64(h + k);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        s0 += __shfl_xor(s0, o, 64);
+        s1 += __shfl_xor(s1, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&acc[0], s0);
+        atomicAdd(&acc[1], s1);
+    }
+}
+
+extern "C" void sa_launch_digest(const void* records, uint64_t bytes, unsigned long long* acc, hipStream_t stream) {
+    const uint64_t npieces = bytes / 16;
+    const unsigned grid = (unsigned)std::min<uint64_t>(256 * 32, (npieces + 255) / 256);
+    hipLaunchKernelGGL(sa_digest_kernel, dim3(grid ? grid : 1), dim3(256), 0, stream, (const uint4*)records, npieces, acc);
 }
 
 extern "C" void sa_launch_pack_slots(const uint8_t* codes, const uint64_t* offs, const uint32_t* lens, uint64_t nseq,

@@ -238,12 +238,90 @@ def test_full_size_peptide_set_sampled_against_oracle():
         off = rng.randrange(0, n - 1 - i - cnt + 1)
         rec = al.fetch_resident(first + off, cnt)
         _check_pairs(al, rec, [(i, i + 1 + off + k) for k in range(cnt)])
-    # size-independent property over a large contiguous block: columns = len1 + gaps and
-    # matches + mismatches + gaps = columns, with mismatches >= 0
-    blk = al.fetch_resident(total // 2, 200000)
+    # size-independent properties over a large contiguous block, computed with the sequence lengths:
+    #   the record's gaps are its UP rows; matches <= min(len1, len2); the rows' LEFT runs plus the DIAG rows consume
+    #   at most len1 columns (the rest is a LEFT run before row 1), so columns = len1 + gaps and
+    #   matches + mismatches + gaps = columns with mismatches >= 0; body bytes past len2 are zero
+    lens = np.array([len(s) for s in seqs], dtype=np.int64)
+    start = total // 2
+    nblk = 200000
+    blk = al.fetch_resident(start, nblk)
+    row_starts = np.array([al.pair_index(sa.TRIANGULAR, i) for i in range(rows + 1)], dtype=np.int64)
+    idx = start + np.arange(nblk, dtype=np.int64)
+    i_of = np.searchsorted(row_starts, idx, side="right") - 1
+    j_of = i_of + 1 + (idx - row_starts[i_of])
+    len1, len2 = lens[i_of], lens[j_of]
     gaps = blk[:, 6].astype(np.int64) | (blk[:, 7].astype(np.int64) << 8)
     matches = blk[:, 4].astype(np.int64) | (blk[:, 5].astype(np.int64) << 8)
-    assert (matches >= 0).all() and (gaps <= 50).all() and (matches <= 50).all()
+    body = blk[:, 8:].astype(np.int64)
+    in_seq = np.arange(body.shape[1])[None, :] < len2[:, None]
+    assert (body[~in_seq] == 0).all()
+    ups = ((body & 1) * in_seq).sum(axis=1)
+    diags = (((body & 1) ^ 1) * in_seq).sum(axis=1)
+    runs = ((body >> 1) * in_seq).sum(axis=1)
+    assert (ups == gaps).all()
+    assert (runs + diags <= len1).all()
+    assert (matches <= diags).all() and (matches <= np.minimum(len1, len2)).all()
+    columns = len1 + gaps
+    assert (columns - matches - gaps >= 0).all() and (columns <= len1 + len2).all()
+    # every row of sequence 2 is crossed once: DIAG rows + UP rows = len2
+    assert (diags + ups == len2).all()
+    score = blk[:, 0:4].copy().view(np.int32)[:, 0].astype(np.int64)
+    assert (score <= 15 * np.minimum(len1, len2)).all() and (score >= -4 * (len1 + len2) - 5 * np.minimum(len1, len2)).all()
+
+
+def test_full_size_peptide_set_both_kernels_give_the_same_records():
+    """BASELINE.json configs[2] at full size on the packed 16-bit kernel and on the 32-bit kernel: every one of the
+    1.25e9 records compared through a device-side digest per block of rows, and one block byte by byte."""
+    seqs, _ = synth.generate(50000, 6, 50, seed=1)
+    a = sa.Aligner()
+    a.upload(seqs)
+    b = sa.Aligner()
+    b.clone_from(a)
+    b.set_pairing(False)
+    rows = a.rows(sa.TRIANGULAR)
+    total = a.pair_count(sa.TRIANGULAR, 0, rows)
+    for al in (a, b):
+        al.prepare_resident(sa.TRIANGULAR, 0, rows)
+        al.run_resident()
+    assert a.last_kernel() == "sa_peptide_pair_kernel<13, 4>" and b.last_kernel() == "sa_peptide_kernel<0, 3>"
+    step = total // 40 + 1
+    for first in range(0, total, step):
+        cnt = min(step, total - first)
+        assert a.digest_resident(first, cnt) == b.digest_resident(first, cnt), first
+    assert a.digest_resident(0, 1000) != a.digest_resident(1, 1000)        # the digest sees positions
+    first = total // 3
+    assert np.array_equal(a.fetch_resident(first, 2_000_000), b.fetch_resident(first, 2_000_000))
+
+
+def test_full_size_protein_set_sampled_against_oracle():
+    """BASELINE.json configs[4] at full size (10 000 proteins of 300-1000 residues, 5.0e7 pairs, 2.1e13 cells, about
+    100 GB of records left in HBM): sampled pairs and both ends against the checker, digest against a second launch."""
+    seqs, _ = synth.generate(10000, 300, 1000, seed=2)
+    al = sa.Aligner(max_seq_len=1000)
+    al.upload(seqs)
+    rows = al.rows(sa.TRIANGULAR)
+    n = len(seqs)
+    total = al.pair_count(sa.TRIANGULAR, 0, rows)
+    assert total == n * (n - 1) // 2 == 49995000
+    al.prepare_resident(sa.TRIANGULAR, 0, rows)
+    al.run_resident()
+    assert al.last_kernel() == "sa_long_pair_kernel<4>"
+    rng = random.Random(77)
+    picks = [(0, 1), (0, n - 1), (n - 2, n - 1), (n - 3, n - 2), (1, 2)]
+    while len(picks) < 340:
+        i = rng.randrange(n - 1)
+        picks.append((i, rng.randrange(i + 1, n)))
+    for i, j in picks:
+        rec = al.fetch_resident(al.pair_index(sa.TRIANGULAR, i) + (j - i - 1), 1)
+        _check_pairs(al, rec, [(i, j)])
+    # a run of consecutive pairs across the end of one row of the schedule and the start of the next
+    first = al.pair_index(sa.TRIANGULAR, 5000) - 20
+    rec = al.fetch_resident(first, 40)
+    _check_pairs(al, rec, [(4999, n - 20 + k) for k in range(20)] + [(5000, 5001 + k) for k in range(20)])
+    d0 = al.digest_resident(0, total)
+    al.run_resident()
+    assert al.digest_resident(0, total) == d0
 
 
 @pytest.mark.gpu
