@@ -158,6 +158,11 @@ int sa_digest_resident(sa_ctx* ctx, uint64_t first, uint64_t n, uint64_t digest[
  * tiles per item from the size of the row range (at least 32 items per workgroup) and launches
  * as many workgroups per CU as registers and LDS let reside there, plus one. */
 int sa_set_tuning(sa_ctx* ctx, uint32_t tiles_per_item, uint32_t wg_per_cu);
+/* width of the TRIANGULAR length buckets in residues (a wave's 64 second sequences, and the two first sequences of a
+ * packed wave, come from one bucket: wide buckets pad short sequences up to the longest of the wave, narrow ones leave
+ * first sequences without a partner); 0 = automatic: exact lengths when every length has 256 sequences or more, wider
+ * otherwise.  Results do not depend on it. */
+int sa_set_bucket_width(sa_ctx* ctx, uint32_t width);
 /* TRIANGULAR work normally runs on kernels that handle two first sequences per wave in packed
  * 16-bit cells; they are used only when the substitution table allows it (S - 2*gap >= 1 everywhere
  * and longest sequence * max(S - 2*gap) <= 1983 when no sequence exceeds 64 residues; 1 .. 24 otherwise).  enable = 0 forces one first

@@ -130,6 +130,7 @@ SIGNATURES = {
     "sa_fetch_resident": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, _u8p]),
     "sa_digest_resident": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
     "sa_set_tuning": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
+    "sa_set_bucket_width": (C.c_int, [C.c_void_p, C.c_uint32]),
     "sa_last_kernel": (C.c_char_p, [C.c_void_p]),
     "sa_set_pairing": (C.c_int, [C.c_void_p, C.c_int]),
     "sa_set_text_layout": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -303,6 +304,9 @@ class Aligner:
 
     def set_tuning(self, tiles_per_item=0, wg_per_cu=0):
         _check(self._lib.sa_set_tuning(self._ctx, tiles_per_item, wg_per_cu))
+
+    def set_bucket_width(self, width):
+        _check(self._lib.sa_set_bucket_width(self._ctx, width))
 
     def set_pairing(self, enable):
         """Two first sequences per wave in the TRIANGULAR peptide kernel (default on); off = one, 32-bit cells."""

@@ -122,6 +122,7 @@ struct sa_ctx {
     bool pairing = true;               // TRIANGULAR peptides: two first sequences per wave where the table allows it
     int64_t sprime_min = 0, sprime_max = 0;   // range of S' = S - 2*gap over the table: decides whether packed cells fit
     uint32_t bucket_width = 1;
+    uint32_t bucket_width_forced = 0;  // sa_set_bucket_width: 0 = from the number of sequences per length
     // sequences (host mirror)
     uint64_t nseq = 0;
     std::vector<uint16_t> len;         // file order
@@ -198,6 +199,7 @@ int ensure_triangular(sa_ctx* c) {
     const uint32_t range = c->max_seq - c->min_seq + 1;
     uint32_t width = (uint32_t)((256ull * range + n - 1) / n);
     width = std::max(1u, std::min(width, 64u));
+    if (c->bucket_width_forced) width = std::max(1u, std::min(c->bucket_width_forced, std::max(range, 1u)));
     const uint32_t nb = (range + width - 1) / width;
     if ((uint64_t)nb * n > (1ull << 28)) return SA_ERR_NOMEM;   // cursor table of more than 1 GiB
     c->nb = nb;
@@ -629,6 +631,15 @@ int sa_set_tuning(sa_ctx* c, uint32_t tiles_per_item, uint32_t wg_per_cu) {
     if (!c) return SA_ERR_ARG;
     if (tiles_per_item) c->tiles_per_item = tiles_per_item;
     if (wg_per_cu) c->wg_per_cu = wg_per_cu;
+    c->resident_ready = false;
+    return SA_OK;
+}
+
+int sa_set_bucket_width(sa_ctx* c, uint32_t width) {
+    if (!c) return SA_ERR_ARG;
+    if (c->inflight) return SA_ERR_STATE;
+    c->bucket_width_forced = width;
+    c->tri_ready = false;          // the bucket order is rebuilt on the next TRIANGULAR use
     c->resident_ready = false;
     return SA_OK;
 }

@@ -5,7 +5,8 @@
 // number of pairs per GPU submission (sa_settings.pairs_per_submit); the sweep runs
 // the whole CSV driver without writing and prints the same kind of table, then a
 // second table for the peptide kernel's own knobs (64-pair tiles per work item,
-// workgroups per CU) measured with the records left on the device.
+// workgroups per CU) and a third for the width of the length buckets, both measured
+// with the records left on the device.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -69,7 +70,7 @@ int main(int argc, char** argv) {
     const double cells = (double)sa_cell_count(ctx, SA_SCHEDULE_TRIANGULAR, 0, rows);
     printf("\nTiles per item\tWaves per CU\tKernel (ms)\tGCUPS\n");
     const uint32_t tiles[] = {2, 4, 8, 16, 32};
-    const uint32_t waves[] = {8, 12, 13};
+    const uint32_t waves[] = {12, 15, 16, 17, 20};     // the library's own choice: what is resident (15 or 16) plus one
     for (uint32_t w : waves)
         for (uint32_t t : tiles) {
             sa_set_tuning(ctx, t, w);
@@ -82,6 +83,21 @@ int main(int argc, char** argv) {
             if (rc) { fprintf(stderr, "kernel sweep: %s\n", sa_strerror(rc)); return 1; }
             printf("%u\t%u\t%.3f\t%.1f\n", t, w, bestms, cells / bestms * 1e-6);
         }
+    // Length buckets: the library's automatic width first (0), then fixed widths.
+    sa_set_tuning(ctx, 16, 17);
+    printf("\nBucket width\tKernel (ms)\tGCUPS\tKernel\n");
+    const uint32_t widths[] = {0, 1, 2, 4, 8, 16, 64};
+    for (uint32_t bw : widths) {
+        sa_set_bucket_width(ctx, bw);
+        rc = sa_prepare_resident(ctx, SA_SCHEDULE_TRIANGULAR, 0, rows);
+        float ms = 0, bestms = 1e30f;
+        for (int rep = 0; rep < 3 && !rc; rep++) {
+            rc = sa_run_resident(ctx, &ms);
+            if (ms < bestms) bestms = ms;
+        }
+        if (rc) { fprintf(stderr, "bucket sweep: %s\n", sa_strerror(rc)); return 1; }
+        printf("%u\t%.3f\t%.1f\t%s\n", bw, bestms, cells / bestms * 1e-6, sa_last_kernel(ctx));
+    }
     sa_destroy(ctx);
     return 0;
 }

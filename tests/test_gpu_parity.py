@@ -216,6 +216,9 @@ def test_tuning_knobs_do_not_change_results():
     for tiles, wg in ((1, 2), (16, 4), (3, 12)):
         al.set_tuning(tiles_per_item=tiles, wg_per_cu=wg)
         assert np.array_equal(al.align(sa.TRIANGULAR), base)
+    for width in (1, 3, 16, 64, 0):
+        al.set_bucket_width(width)
+        assert np.array_equal(al.align(sa.TRIANGULAR), base)
 
 
 def test_full_size_peptide_set_sampled_against_oracle():
@@ -348,7 +351,8 @@ def test_tuner_prints_its_two_tables(tmp_path):
     assert out.returncode == 0, out.stderr
     assert "Pairs per submission\tTime (s)\tPairs/s" in out.stdout
     assert "Tiles per item\tWaves per CU\tKernel (ms)\tGCUPS" in out.stdout
-    assert out.stdout.count("\n") >= 6 + 1 + 2 + 10
+    assert "Bucket width\tKernel (ms)\tGCUPS\tKernel" in out.stdout
+    assert out.stdout.count("\n") >= 6 + 1 + 2 + 25 + 2 + 7
 
 
 # ---- the two TRIANGULAR peptide kernels: paired (two first sequences per wave, packed 16-bit cells,
