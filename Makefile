@@ -22,8 +22,8 @@ sequencealigner_amd/sa_dataset: $(CSRC)/sa_dataset.c
 	gcc -O2 -Wall -Wextra -o $@ $(CSRC)/sa_dataset.c
 $(MAIN): $(CSRC)/sa_main.cpp $(LIB)
 	$(HIPCC) -O2 -std=c++17 -Wall -o $@ $(CSRC)/sa_main.cpp -Lsequencealigner_amd -lsa_hip -Wl,-rpath,'$$ORIGIN'
-$(LIB): $(CSRC)/sa_kernel_common.h $(CSRC)/sa_traceback.h $(CSRC)/sa_pair_common.h $(CSRC)/sa_parallel.h $(CSRC)/sa_kernels.hip $(CSRC)/sa_kernels_pair.hip $(CSRC)/sa_kernels_long.hip $(CSRC)/sa_kernels_long_pair.hip $(CSRC)/sa_format.hip $(CSRC)/sa_noalloc.hip $(CSRC)/sa_api.cpp $(CSRC)/sa_host.cpp $(CSRC)/sa_device.h include/sa_hip.h include/sa_host.h
-	$(HIPCC) $(HIPFLAGS) -shared -pthread -o $@ $(CSRC)/sa_kernels.hip $(CSRC)/sa_kernels_pair.hip $(CSRC)/sa_kernels_long.hip $(CSRC)/sa_kernels_long_pair.hip $(CSRC)/sa_format.hip $(CSRC)/sa_noalloc.hip $(CSRC)/sa_api.cpp $(CSRC)/sa_host.cpp
+$(LIB): $(CSRC)/sa_kernel_common.h $(CSRC)/sa_traceback.h $(CSRC)/sa_pair_common.h $(CSRC)/sa_parallel.h $(CSRC)/sa_kernels.hip $(CSRC)/sa_kernels_pair.hip $(CSRC)/sa_kernels_long.hip $(CSRC)/sa_kernels_long_pair.hip $(CSRC)/sa_kernels_coop.hip $(CSRC)/sa_format.hip $(CSRC)/sa_noalloc.hip $(CSRC)/sa_api.cpp $(CSRC)/sa_host.cpp $(CSRC)/sa_device.h include/sa_hip.h include/sa_host.h
+	$(HIPCC) $(HIPFLAGS) -shared -pthread -o $@ $(CSRC)/sa_kernels.hip $(CSRC)/sa_kernels_pair.hip $(CSRC)/sa_kernels_long.hip $(CSRC)/sa_kernels_long_pair.hip $(CSRC)/sa_kernels_coop.hip $(CSRC)/sa_format.hip $(CSRC)/sa_noalloc.hip $(CSRC)/sa_api.cpp $(CSRC)/sa_host.cpp
 
 oracle:
 	$(MAKE) -C oracle all

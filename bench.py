@@ -170,6 +170,32 @@ def resident_measurement(sa, synth, name, device, launches=2, pairing=True):
     return out
 
 
+def few_pairs_measurement(sa, synth, device):
+    """Submissions of few long pairs, where a pair per lane leaves the chip idle: the wave-per-pair kernel against the
+    pair-per-lane kernel on 64 adjacent pairs of 4096-residue sequences and on 150 proteins all-vs-all."""
+    out = {}
+    cases = {"adjacent_65x4096": (65, 4096, 4096, 5, sa.ADJACENT), "triangular_150_proteins": (150, 300, 1000, 2, sa.TRIANGULAR)}
+    for name, (n, lo, hi, seed, schedule) in cases.items():
+        seqs, _ = synth.generate(n, lo, hi, seed)
+        al = sa.Aligner(device=device, max_seq_len=hi)
+        al.upload(seqs)
+        rows = al.rows(schedule)
+        res = {"pairs": al.pair_count(schedule, 0, rows), "cells": al.cell_count(schedule, 0, rows)}
+        for mode, key in ((1, "wave_per_pair"), (-1, "pair_per_lane")):
+            al.set_cooperative(mode)
+            al.prepare_resident(schedule, 0, rows)
+            al.run_resident()
+            ms = min(al.run_resident() for _ in range(3))
+            res[key] = {"kernel": al.last_kernel(), "kernel_ms": round(ms, 3), "gcups": round(res["cells"] / ms / 1e6, 1)}
+        al.set_cooperative(0)
+        al.prepare_resident(schedule, 0, rows)
+        al.run_resident()
+        res["library_choice"] = al.last_kernel()
+        al.close()
+        out[name] = res
+    return out
+
+
 def counter_rates(rec, k_ms):
     """Rates from the per-launch counter totals of profiles/ and the kernel time measured in this run."""
     sec = k_ms * 1e-3
@@ -386,6 +412,7 @@ def main():
                     mega_path = os.path.join(tmp.name, "mega.csv")
                     synth.make_mega(os.path.join(ROOT, "tests", "golden", "avpdb.csv"), mega_path)
                     extra["e2e_mega"] = e2e_mega(sa, mega_path, tmp.name, local_rank)
+                    extra["few_long_pairs"] = few_pairs_measurement(sa, synth, local_rank)
                     extra["proteins2k"] = resident_measurement(sa, synth, "proteins2k", local_rank)
                     extra["proteins10k"] = resident_measurement(sa, synth, "proteins10k", local_rank, launches=1)
                 out["extra"] = extra

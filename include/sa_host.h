@@ -47,6 +47,7 @@ typedef struct {
     int32_t device_format;            /* 1 (default): rows of CSV text are written on the GPU (sa_submit_text); 0: records come back and host threads format them */
     char scoring_matrix_file[4096];   /* SA_SCORING_MATRIX: file with the 20x20 substitution matrix (sa_load_matrix_file); empty = the
                                          reference's BLOSUM50 literal (include/scoring.h:16-36) */
+    int32_t cooperative;              /* SA_COOPERATIVE: sa_set_cooperative() of every context; default 0 (by pair count) */
 } sa_settings;
 
 typedef struct {

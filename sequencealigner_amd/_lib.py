@@ -70,6 +70,7 @@ class Settings(C.Structure):
         ("pairing", C.c_int32),
         ("device_format", C.c_int32),
         ("scoring_matrix_file", C.c_char * 4096),
+        ("cooperative", C.c_int32),
     ]
 
 
@@ -133,6 +134,7 @@ SIGNATURES = {
     "sa_set_bucket_width": (C.c_int, [C.c_void_p, C.c_uint32]),
     "sa_last_kernel": (C.c_char_p, [C.c_void_p]),
     "sa_set_pairing": (C.c_int, [C.c_void_p, C.c_int]),
+    "sa_set_cooperative": (C.c_int, [C.c_void_p, C.c_int]),
     "sa_set_text_layout": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sa_upload_passthrough": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.c_uint64]),
     "sa_submit_text": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64]),
@@ -304,6 +306,10 @@ class Aligner:
 
     def set_tuning(self, tiles_per_item=0, wg_per_cu=0):
         _check(self._lib.sa_set_tuning(self._ctx, tiles_per_item, wg_per_cu))
+
+    def set_cooperative(self, mode):
+        """Wave-per-pair kernel for long sequences: 0 = by pair count (default), 1 = always, -1 = never."""
+        _check(self._lib.sa_set_cooperative(self._ctx, mode))
 
     def set_bucket_width(self, width):
         _check(self._lib.sa_set_bucket_width(self._ctx, width))

@@ -27,6 +27,7 @@ extern "C" void sa_launch_peptide_pair(int ng, const SaPepParams* p, unsigned gr
 extern "C" size_t sa_format_scan_bytes(uint64_t n);
 extern "C" hipError_t sa_launch_format(const SaFormatParams* F, void* scan_tmp, size_t scan_bytes, hipStream_t stream);
 extern "C" void sa_launch_long_pair(const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream);
+extern "C" void sa_launch_coop(const SaPepParams* p, unsigned grid, hipStream_t stream);
 extern "C" void sa_launch_long(int mode, const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream);
 
 namespace {
@@ -100,6 +101,7 @@ struct Work {                 // one submitted (or prepared) row range
     uint64_t first_pair = 0, npairs = 0;
     bool busy = false;
     bool paired = false;      // items were built for the paired kernel
+    bool coop = false;        // items are single pairs for the wave-per-pair kernel
     // text submissions: row lengths, row offsets, text, total bytes, scan scratch; pinned total and text
     DevBuf lens, offs, text, total, scan_tmp;
     PinBuf host_total;
@@ -122,6 +124,7 @@ struct sa_ctx {
     bool pairing = true;               // TRIANGULAR peptides: two first sequences per wave where the table allows it
     int64_t sprime_min = 0, sprime_max = 0;   // range of S' = S - 2*gap over the table: decides whether packed cells fit
     uint32_t bucket_width = 1;
+    int coop_mode = 0;                 // wave-per-pair kernel for long sequences: 0 = when a submission has few pairs, 1 always, -1 never
     uint32_t bucket_width_forced = 0;  // sa_set_bucket_width: 0 = from the number of sequences per length
     // sequences (host mirror)
     uint64_t nseq = 0;
@@ -139,6 +142,7 @@ struct sa_ctx {
     std::vector<uint32_t> fi_sorted;     // [nseq] file index of each bucket-order slot
     std::vector<uint32_t> cursor;        // [nseq][nb] entries of bucket b with file index <= p
     // device
+    DevBuf d_coop;                     // scratch of the wave-per-pair kernel
     DevBuf d_codes, d_len, d_codes_t, d_fi_sorted, d_len_sorted, d_bucket_base, d_cursor, d_sprime, d_spill, d_phase, d_bcol, d_codes_s;
     bool phase_timers = false;
     // device-side text
@@ -355,6 +359,19 @@ int build_items(sa_ctx* c, int schedule, uint64_t r0, uint64_t r1, std::vector<S
 // long sequences: direction rows per strip, sized by the longest sequence uploaded (rows are walked eight at a time)
 uint32_t long_dir_rows(const sa_ctx* c) { return (c->max_seq + 7u) & ~7u; }
 
+// The wave-per-pair kernel (sa_kernels_coop.hip) takes a submission of long sequences when its pairs would fill only
+// a fraction of the chip's lanes on the pair-per-lane kernels: up to one wave's worth of pairs per CU.
+bool use_coop(const sa_ctx* c, uint64_t npairs) {
+    if (c->lslot <= SA_LP || c->coop_mode < 0 || npairs == 0) return false;
+    return c->coop_mode > 0 || npairs <= 64ull * (uint64_t)c->ncu;
+}
+// its scratch per workgroup, KiB: direction blocks (strips x 16-step blocks x 256 B), two border columns, row notes
+uint32_t coop_kib_per_wg(const sa_ctx* c) {
+    const uint64_t steps_cap = c->lslot + 128;
+    const uint64_t bytes = (uint64_t)(c->lslot / 64) * (steps_cap / 16) * 256 + 2 * steps_cap * 4 + 2 * (c->lslot + 64) * 2;
+    return (uint32_t)((bytes + 1023) / 1024);
+}
+
 // global scratch of one workgroup: direction rows (and, for long sequences, the strip border columns)
 size_t spill_bytes_per_wg(const sa_ctx* c) {
     if (!is_long(c)) return (size_t)2 * SA_LP * 1024;      // two sets of direction rows for the paired kernel
@@ -396,7 +413,7 @@ int ensure_spill(sa_ctx* c, uint32_t grid) {
 // queue the kernels of one row range on the compute stream
 int launch_work(sa_ctx* c, Work& w, bool timed) {
     if (w.npairs == 0 || w.nitems == 0) return SA_OK;
-    if (is_long(c) && c->spill_grid == 0) {
+    if (is_long(c) && c->spill_grid == 0 && !w.coop) {
         // First launch after an upload: the records of this row range are allocated by now, so what is free tells how
         // many workgroups' direction areas fit.  A full grid (16 workgroups per CU) of 1000-residue proteins takes
         // 125 GiB; with less the launch runs fewer waves per SIMD.  16 GiB stay free for the second slot's records.
@@ -408,7 +425,7 @@ int launch_work(sa_ctx* c, Work& w, bool timed) {
         c->spill_budget = std::max<uint64_t>(std::min<uint64_t>(room, (uint64_t)free_b / 4 * 3), 1ull << 30);
     }
     const uint32_t grid = grid_for(c);
-    int rc = ensure_spill(c, grid);
+    int rc = w.coop ? SA_OK : ensure_spill(c, grid);
     if (rc) return rc;
     SA_HIP_TRY(hipMemsetAsync(w.counter.p, 0, 256, c->compute));
     SaPepParams P;
@@ -443,7 +460,15 @@ int launch_work(sa_ctx* c, Work& w, bool timed) {
     P.lslot = c->lslot;
     P.bcol = (int32_t*)c->d_bcol.p;
     const bool tri = w.schedule == SA_SCHEDULE_TRIANGULAR;
-    if (is_long(c) && tri && w.paired) {
+    if (w.coop) {
+        const uint32_t cgrid = (uint32_t)std::min<uint64_t>(w.nitems, (uint64_t)c->ncu * 16);
+        const uint32_t kib = coop_kib_per_wg(c);
+        if ((rc = c->d_coop.reserve((size_t)cgrid * kib * 1024))) return rc;
+        P.spill = (uint32_t*)c->d_coop.p;
+        P.spill_rows = kib;
+        sa_launch_coop(&P, cgrid, c->compute);
+        c->last_kernel = "sa_coop_kernel";
+    } else if (is_long(c) && tri && w.paired) {
         // + 64: rows read table entries two groups ahead, up to 16 bytes past the last profile row; + 2 lslot: the two first sequences
         sa_launch_long_pair(&P, grid, SA_LDS_PROF_BYTES + 64 + 2 * c->lslot, c->compute);
         c->last_kernel = "sa_long_pair_kernel<4>";
@@ -467,12 +492,35 @@ int launch_work(sa_ctx* c, Work& w, bool timed) {
 int prepare_work(sa_ctx* c, Work& w, int schedule, uint64_t r0, uint64_t r1, bool need_host) {
     std::vector<SaItem> items;
     bool paired = true;
-    int rc = build_items(c, schedule, r0, r1, items, paired);
+    int rc = SA_OK;
+    w.first_pair = sa_pair_index(c, schedule, r0);
+    w.npairs = sa_pair_count(c, schedule, r0, r1);
+    w.coop = use_coop(c, w.npairs);
+    if (w.coop) {
+        // one pair per item, the most expensive first (cost = strips x steps per strip)
+        paired = false;
+        items.reserve(w.npairs);
+        SaItem it;
+        memset(&it, 0, sizeof(it));
+        it.count = 1;
+        uint64_t idx = 0;
+        for (uint64_t i = r0; i < r1; i++) {
+            const uint64_t j_end = schedule == SA_SCHEDULE_ADJACENT ? i + 2 : c->nseq;
+            for (uint64_t j = i + 1; j < j_end; j++, idx++) {
+                it.p = (uint32_t)i; it.v0 = (uint32_t)j;
+                it.b0 = (uint32_t)idx; it.c0 = (uint32_t)(idx >> 32);
+                items.push_back(it);
+            }
+        }
+        std::stable_sort(items.begin(), items.end(), [c](const SaItem& a, const SaItem& b) {
+            return (uint64_t)((c->len[a.p] + 63) / 64) * (c->len[a.v0] + 63) > (uint64_t)((c->len[b.p] + 63) / 64) * (c->len[b.v0] + 63);
+        });
+    } else {
+        rc = build_items(c, schedule, r0, r1, items, paired);
+    }
     if (rc) return rc;
     w.schedule = schedule;
     w.paired = paired;
-    w.first_pair = sa_pair_index(c, schedule, r0);
-    w.npairs = sa_pair_count(c, schedule, r0, r1);
     w.nitems = (uint32_t)items.size();
     if ((rc = w.counter.reserve(256))) return rc;
     if ((rc = w.items.reserve(std::max<size_t>(16, items.size() * sizeof(SaItem))))) return rc;
@@ -618,7 +666,7 @@ void sa_destroy(sa_ctx* c) {
     free_work(c->slots[0]); free_work(c->slots[1]); free_work(c->resident);
     c->d_codes.release(); c->d_len.release(); c->d_codes_t.release(); c->d_fi_sorted.release();
     c->d_len_sorted.release(); c->d_bucket_base.release(); c->d_cursor.release(); c->d_sprime.release();
-    c->d_spill.release(); c->d_bcol.release(); c->d_codes_s.release();
+    c->d_spill.release(); c->d_bcol.release(); c->d_codes_s.release(); c->d_coop.release();
     c->d_other.release(); c->d_other_off.release();
     c->text_ring[0].release(); c->text_ring[1].release();
     c->d_phase.release();
@@ -1076,6 +1124,14 @@ int sa_digest_resident(sa_ctx* c, uint64_t first, uint64_t n, uint64_t digest[2]
     SA_HIP_TRY(hipGetLastError());
     SA_HIP_TRY(hipMemcpyAsync(digest, acc, 16, hipMemcpyDeviceToHost, c->compute));
     SA_HIP_TRY(hipStreamSynchronize(c->compute));
+    return SA_OK;
+}
+
+int sa_set_cooperative(sa_ctx* c, int mode) {
+    if (!c || mode < -1 || mode > 1) return SA_ERR_ARG;
+    if (c->inflight) return SA_ERR_STATE;
+    c->coop_mode = mode;
+    c->resident_ready = false;
     return SA_OK;
 }
 

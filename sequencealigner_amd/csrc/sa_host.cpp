@@ -337,6 +337,7 @@ int sa_settings_load(sa_settings* st, const char* path) {
         else if (k == "BATCH_SIZE") { if (num(x)) st->batch_size = (uint32_t)x; }
         else if (k == "SA_SCHEDULE") { if (num(x)) st->schedule = (int32_t)x; }
         else if (k == "SA_NUM_DEVICES") { if (num(x)) st->num_devices = (int32_t)x; }
+        else if (k == "SA_COOPERATIVE") { if (num(x)) st->cooperative = (int32_t)x; }
         else if (k == "SA_SCORING_MATRIX") { if (!parse_c_string(v, st->scoring_matrix_file, sizeof(st->scoring_matrix_file))) st->scoring_matrix_file[0] = 0; }
     }
     fclose(f);
@@ -436,6 +437,7 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
     for (int d = 0; d < ndev; d++) {
         rc = sa_init(&ctx[(size_t)d], S, st->gap_penalty, max_len, st->devices[d]);
         if (rc == SA_OK) rc = sa_set_pairing(ctx[(size_t)d], st->pairing);
+        if (rc == SA_OK) rc = sa_set_cooperative(ctx[(size_t)d], st->cooperative);
         if (rc) { cleanup(); return fail(rc); }
     }
 

@@ -1,0 +1,209 @@
+// sa_kernels_coop.hip -- one wave per pair: the anti-diagonal sweep for submissions of FEW long pairs.
+//
+// The pair-per-lane kernels (sa_kernels_long*.hip) need 64 pairs to fill one wave and thousands of
+// waves to fill the chip; a submission of a few hundred protein pairs (ADJACENT over a small file,
+// a short TRIANGULAR row range) leaves the GPU idle and takes as long as 64 pairs on one lane each.
+// Here the 64 lanes of a wave share ONE pair (reference: include/seqalign.h:47-88, one call of
+// align_sequences):
+//
+//  * fill: the matrix is swept in strips of 64 columns, lane l owns column 64 s + l of the strip, and
+//    at step t it computes the cell of row t - l: the cells of one step lie on an anti-diagonal.
+//    Its three operands: UP is its own result of the step before; LEFT is lane l-1's result of the
+//    step before, fetched with one DPP wave shift (wave_shr:1); DIAG is what LEFT was one step earlier.
+//    The row residue travels the same way: lane l needs seq2[t - l], which lane l-1 held a step
+//    before -- a second DPP shift, lane 0 taking the next residue.  The substitution score is one LDS
+//    read of the table S' indexed by the lane's column residue and the travelling row residue.
+//    Cells are the tagged 32-bit cells of sa_kernel_common.h (4 D + tag, DIAG 3 > UP 1 > LEFT 0 decided by
+//    the three-way maximum itself).  Rows above the matrix are fed a residue code whose score is
+//    hugely negative: by induction those cells stay at the border value D = 0, so a lane needs no test
+//    for "has my column started".  The last column of a strip is collected lane by lane
+//    (v_readlane + v_writelane) and handed to the next strip as its left border, 64 rows at a time.
+//  * directions: every lane shifts its cell's tag into a dword, 16 steps per dword, and the wave stores
+//    the 64 dwords of a 16-step block with one coalesced 256-byte store.  The tag of cell (r, c) is at
+//    bits 2 (t mod 16) of dword [strip][t / 16][c mod 64], t = r + c mod 64.
+//  * traceback: one walk per wave, all in scalar registers; the 64 dwords of the block the walk is in
+//    sit in one VGPR (one lane each) and are picked with v_readlane; leaving the block loads the next.
+//    Per row the walk notes how the row was left (LEFT moves * 2 + UP/DIAG, the record's uint16) and
+//    where; matches and gaps are then counted 64 rows at a time.
+//
+// Work items: one pair each, {p = sequence 1, v0 = sequence 2 (file indices), b0 | c0 << 32 = record
+// index relative to the submission's first pair}.  Records are the long-sequence records of
+// sa_device.h, byte-identical to those of sa_long_kernel.
+#include "sa_kernel_common.h"
+
+#define SA_COOP_NEG_CODE 21                 /* row residue of the rows above the matrix */
+#define SA_COOP_DPP_WAVE_SHR1 0x138         /* DPP control: lane l reads lane l-1 across the whole wave */
+
+__device__ __forceinline__ int sa_wave_shr1(int old_for_lane0, int v) {
+    // lane 0 has no source lane: with bound_ctrl off it keeps `old`
+    return __builtin_amdgcn_update_dpp(old_for_lane0, v, SA_COOP_DPP_WAVE_SHR1, 0xf, 0xf, false);
+}
+
+// v_writelane_b32: one lane of `dst` takes a wave-uniform value.  Value and lane index are both scalars, and a vector
+// instruction of this generation reads one scalar register only: the lane index goes through M0 (one wait state
+// after the scalar move).  When the index was computed from v_readlane results (the walk), the move itself must
+// come four wait states after them.
+__device__ __forceinline__ int sa_writelane_step(int value, int lane_index, int dst) {
+    value = __builtin_amdgcn_readfirstlane(value);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(dst) : "s"(value), "s"(lane_index));  /* M0 is otherwise unused in this kernel */
+    return dst;
+}
+__device__ __forceinline__ uint32_t sa_writelane(int value, int lane_index, uint32_t dst) {
+    value = __builtin_amdgcn_readfirstlane(value);
+    lane_index = __builtin_amdgcn_readfirstlane(lane_index);
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(dst) : "s"(value), "s"(lane_index));  /* M0 is otherwise unused in this kernel */
+    return dst;
+}
+
+__global__ void __launch_bounds__(64, 4) sa_coop_kernel(const SaPepParams P) {
+    __shared__ int32_t tab[21 * 32];        // tab[a * 32 + b] = 4 S'[a][b] + 3; b = SA_COOP_NEG_CODE: far below any score
+    const int lane = threadIdx.x;
+    const uint32_t lslot = P.lslot;
+    const uint32_t strips_cap = lslot >> 6;
+    const uint32_t steps_cap = lslot + 128;                 // steps of a strip, rounded up to 64, at most
+    const uint32_t blocks_cap = steps_cap >> 4;
+    // per-workgroup scratch: direction blocks | two border columns | per-row notes of the walk
+    uint8_t* const area = reinterpret_cast<uint8_t*>(P.spill) + (size_t)blockIdx.x * P.spill_rows * 1024;
+    uint32_t* const dirs = reinterpret_cast<uint32_t*>(area);
+    int32_t* const bcol = reinterpret_cast<int32_t*>(area + (size_t)strips_cap * blocks_cap * 256);
+    uint16_t* const note_l = reinterpret_cast<uint16_t*>(bcol + 2 * steps_cap);
+    uint16_t* const note_c = note_l + lslot + 64;
+
+    for (int e = lane; e < 21 * 32; e += 64) {
+        const int a = e >> 5, b = e & 31;
+        int v = SA_TAG_TABLE(P.sprime[a * SA_SPRIME_STRIDE + (b <= 20 ? b : 20)]) + 1;     // + 1: DIAG operand is LEFT's clean value
+        if (b == SA_COOP_NEG_CODE) v = -(1 << 29);
+        tab[e] = v;
+    }
+    __syncthreads();
+
+    for (;;) {
+        uint32_t it = 0;
+        if (lane == 0) it = atomicAdd(P.counter, 1u);
+        it = __builtin_amdgcn_readfirstlane(it);
+        if (it >= P.nitems) break;
+        const SaItem item = P.items[it];
+        const uint32_t s1 = item.p, s2 = item.v0;
+        const int len1 = __builtin_amdgcn_readfirstlane((int)P.len_fo[s1]);
+        const int len2 = __builtin_amdgcn_readfirstlane((int)P.len_fo[s2]);
+        const uint8_t* const seq1 = P.codes_fo + (size_t)s1 * lslot;
+        const uint8_t* const seq2 = P.codes_fo + (size_t)s2 * lslot;
+        uint8_t* const rec = P.out + (((uint64_t)item.c0 << 32) | item.b0) * P.stride;
+        const int nstrips = (len1 + 63) >> 6;
+        const int nsuper = (len2 + 63 + 63) >> 6;          // 64-step super-blocks of a strip: steps 0 .. len2 + 62
+        const int lstar = (len1 - 1) & 63, tstar = len2 - 1 + lstar;
+        int dfinal = 0;
+
+        // ------------------------------------------------------------------ fill
+        for (int s = 0; s < nstrips; s++) {
+            const int a32 = (int)seq1[64 * s + lane] * 32 * 4;       // byte offset of the lane's table row (padding: code 20)
+            const int32_t* bin = bcol + (size_t)(s & 1) * steps_cap;
+            int32_t* bout = bcol + (size_t)((s + 1) & 1) * steps_cap;
+            const bool first_strip = s == 0, more = s + 1 < nstrips;
+            int up = 1;                                  // 4 * 0 + 1: the border row
+            int left = first_strip ? 0 : bin[0];         // lane 0: clean value of (row 0, column 64 s - 1); other lanes: rows above the matrix
+            if (lane != 0) left = 0;
+            int left_prev = 0;                           // what LEFT was a step ago = the DIAG operand's clean value
+            int b = lane == 0 ? (int)seq2[0] : SA_COOP_NEG_CODE;
+            uint32_t acc = 0;
+            int colbuf = 0;
+            for (int sb = 0; sb < nsuper; sb++) {
+                // rows 64 sb + 1 .. 64 sb + 64 for lane 0's next steps: residues and the border column
+                const int rown = 64 * sb + 1 + lane;
+                const int resin = rown < (int)lslot ? (int)seq2[rown] : SA_PAD_CODE;
+                const int colin = first_strip ? 0 : bin[rown];
+#pragma unroll
+                for (int blk = 0; blk < 4; blk++) {
+#pragma unroll
+                    for (int u = 0; u < 16; u++) {
+                        const int t = 64 * sb + 16 * blk + u;
+                        const int tl = 16 * blk + u;                     // t mod 64, a constant after unrolling
+                        const int T = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(tab) + a32 + b * 4);
+                        const int m = left_prev + T;
+                        const int h = max3i(m, up, left);
+                        acc = __builtin_amdgcn_alignbit((uint32_t)h, acc, 2);
+                        const int zl = h & ~3;
+                        up = zl | 1;
+                        left_prev = left;
+                        // the strip's last column, row t - 63, for the next strip
+                        const int last = __builtin_amdgcn_readlane(zl, 63);
+                        colbuf = sa_writelane_step(last, tl, colbuf);
+                        if (t == tstar && s == nstrips - 1) dfinal = __builtin_amdgcn_readlane(zl, lstar) >> 2;
+                        // next step's LEFT and row residue come from the lane on the left; lane 0 takes the border
+                        // column's next row and the next residue
+                        const int nb = __builtin_amdgcn_readlane(colin, tl);
+                        const int nr = __builtin_amdgcn_readlane(resin, tl);
+                        left = sa_wave_shr1(nb, zl);
+                        b = sa_wave_shr1(nr, b);
+                    }
+                    dirs[((size_t)s * blocks_cap + 4 * sb + blk) * 64 + lane] = acc;
+                }
+                // colbuf lane i = last column of row 64 sb + i - 63
+                if (more) {
+                    const int r = 64 * sb + lane - 63;
+                    if (r >= 0) bout[r] = colbuf;
+                }
+            }
+            __syncthreads();      // border column and direction blocks are complete before anyone reads them
+        }
+
+        // ------------------------------------------------------------- traceback
+        // State in scalar registers: i rows and j columns still to go, run = LEFT moves taken in the current row.
+        int i = len2, j = len1, run = 0;
+        int cur_s = -1, cur_k = -1;
+        uint32_t w = 0;                       // the direction block the walk is in: lane l holds column l's dword
+        uint32_t out_l = 0, out_c = 0;        // notes of 64 rows, lane r mod 64
+        while (i > 0) {
+            int tag = SA_TAG_UP;              // left border: UP
+            if (j > 0) {
+                const int c = j - 1, l = c & 63, sidx = c >> 6, t = i - 1 + l, k = t >> 4;
+                if (sidx != cur_s || k != cur_k) {
+                    w = dirs[((size_t)sidx * blocks_cap + k) * 64 + lane];
+                    cur_s = sidx; cur_k = k;
+                }
+                tag = (int)((__builtin_amdgcn_readlane(w, l) >> (2 * (t & 15))) & 3u);
+            }
+            if (tag == SA_TAG_LEFT) { run++; j--; continue; }
+            const int row = i - 1;
+            const int note = 2 * run + (tag == SA_TAG_UP ? 1 : 0);
+            out_l = sa_writelane(note, row & 63, out_l);
+            out_c = sa_writelane(j > 0 ? j - 1 : 0, row & 63, out_c);
+            if ((row & 63) == 0) {            // rows row .. row + 63 are noted: write them
+                if (row + lane < len2) { note_l[row + lane] = (uint16_t)out_l; note_c[row + lane] = (uint16_t)out_c; }
+            }
+            if (tag == SA_TAG_DIAG) j--;
+            i--;
+            run = 0;
+        }
+        __syncthreads();
+
+        // ------------------------------------------------------ record, 64 rows at a time
+        int matches = 0, gaps = 0;
+        for (int r0 = 0; r0 < len2; r0 += 64) {
+            const int r = r0 + lane;
+            if (r < len2) {
+                const uint32_t L = note_l[r];
+                if (L & 1) gaps++;
+                else if (seq1[note_c[r]] == seq2[r]) matches++;
+                *reinterpret_cast<uint16_t*>(rec + SA_LONG_HEADER_BYTES + 2 * (size_t)r) = (uint16_t)L;
+            }
+        }
+        // body bytes past the last row are zero, so that equal inputs give equal records
+        for (uint32_t o = SA_LONG_HEADER_BYTES + 2 * (uint32_t)len2 + 2 * lane; o + 1 < P.stride; o += 128)
+            *reinterpret_cast<uint16_t*>(rec + o) = 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            matches += __shfl_xor(matches, o, 64);
+            gaps += __shfl_xor(gaps, o, 64);
+        }
+        if (lane == 0) {
+            const int score = dfinal + (len1 + len2) * P.gap;
+            *reinterpret_cast<uint4*>(rec) = make_uint4((uint32_t)score, (uint32_t)matches, (uint32_t)gaps, 0u);
+        }
+        __syncthreads();          // the notes and blocks are reused by the next pair
+    }
+}
+
+extern "C" void sa_launch_coop(const SaPepParams* p, unsigned grid, hipStream_t stream) {
+    hipLaunchKernelGGL(sa_coop_kernel, dim3(grid), dim3(64), 0, stream, *p);
+}

@@ -130,15 +130,17 @@ def test_asymmetric_matrix_and_length_64():
     _check_pairs(al, rec, [(k, k + 1) for k in range(n - 1)], gap=-3, matrix=matrix)
 
 
+@pytest.mark.parametrize("cooperative", [-1, 1])
 @pytest.mark.parametrize("schedule", [sa.ADJACENT, sa.TRIANGULAR])
 @pytest.mark.parametrize(
     "n,lo,hi,seed",
     [(120, 1, 300, 6), (64, 128, 128, 7), (70, 60, 70, 8), (100, 300, 1000, 2), (300, 65, 66, 9)],
 )
-def test_long_sequences_csv_equal_oracle(tmp_path, schedule, n, lo, hi, seed):
-    """Sequences longer than 64 residues run through the 64-column strip kernel."""
+def test_long_sequences_csv_equal_oracle(tmp_path, schedule, n, lo, hi, seed, cooperative):
+    """Sequences longer than 64 residues: the pair-per-lane strip kernels (cooperative -1) and the wave-per-pair
+    kernel (cooperative 1)."""
     seqs, labels = synth.generate(n, lo, hi, seed)
-    _csv_case(tmp_path, seqs, labels, schedule, max_seq_len=hi + 1)
+    _csv_case(tmp_path, seqs, labels, schedule, max_seq_len=hi + 1, cooperative=cooperative)
 
 
 def test_long_sequences_low_complexity_and_gap_runs(tmp_path):
@@ -146,8 +148,9 @@ def test_long_sequences_low_complexity_and_gap_runs(tmp_path):
     seqs = [("".join(rng.choice("AW") for _ in range(rng.randint(1, 400)))).encode() for _ in range(60)]
     seqs += [b"A" * 700, b"W" * 2, b"A" * 129, b"AW" * 200]
     labels = [k & 1 for k in range(len(seqs))]
-    _csv_case(tmp_path, seqs, labels, sa.TRIANGULAR, max_seq_len=701)
-    _csv_case(tmp_path, seqs, labels, sa.ADJACENT, gap=-1, max_seq_len=701)
+    for cooperative in (-1, 1):
+        _csv_case(tmp_path, seqs, labels, sa.TRIANGULAR, max_seq_len=701, cooperative=cooperative)
+        _csv_case(tmp_path, seqs, labels, sa.ADJACENT, gap=-1, max_seq_len=701, cooperative=cooperative)
 
 
 def test_longest_supported_sequences():
@@ -156,10 +159,13 @@ def test_longest_supported_sequences():
     al = sa.Aligner(max_seq_len=4096)
     al.upload(seqs)
     assert al.row_bytes == 2
-    rec = al.align(sa.TRIANGULAR)
-    _check_pairs(al, rec, _tri_pairs(len(seqs), 0, len(seqs) - 1))
-    rec = al.align(sa.ADJACENT)
-    _check_pairs(al, rec, [(k, k + 1) for k in range(len(seqs) - 1)])
+    for cooperative, kernel in ((-1, "sa_long_"), (1, "sa_coop_kernel"), (0, "sa_coop_kernel")):
+        al.set_cooperative(cooperative)
+        rec = al.align(sa.TRIANGULAR)
+        assert al.last_kernel().startswith(kernel)
+        _check_pairs(al, rec, _tri_pairs(len(seqs), 0, len(seqs) - 1))
+        rec = al.align(sa.ADJACENT)
+        _check_pairs(al, rec, [(k, k + 1) for k in range(len(seqs) - 1)])
 
 
 def test_row_ranges_and_shards_concatenate_to_the_whole():
@@ -453,12 +459,19 @@ def test_long_paired_and_unpaired_kernels_give_identical_records(n, lo, hi, seed
     seqs = ["".join(rng.choice(alphabet) for _ in range(rng.randint(lo, hi))) for _ in range(n)]
     al = sa.Aligner(max_seq_len=hi)
     al.upload(seqs)
+    al.set_cooperative(-1)
     assert any(it[5] != 0xFFFFFFFF for it in al.work_items(sa.TRIANGULAR, 0, n - 1).tolist())
     paired = al.align(sa.TRIANGULAR)
+    assert al.last_kernel() == "sa_long_pair_kernel<4>"
     al.set_pairing(False)
     assert all(it[5] == 0xFFFFFFFF for it in al.work_items(sa.TRIANGULAR, 0, n - 1).tolist())
     unpaired = al.align(sa.TRIANGULAR)
+    assert al.last_kernel() == "sa_long_kernel<0, 2>"
     assert np.array_equal(paired, unpaired)
+    # and the wave-per-pair kernel: the same bytes again
+    al.set_cooperative(1)
+    assert np.array_equal(al.align(sa.TRIANGULAR), paired)
+    assert al.last_kernel() == "sa_coop_kernel"
     for i in [0, n - 2] + [rng.randrange(n - 1) for _ in range(3)]:
         first = al.pair_index(sa.TRIANGULAR, i)
         pairs = [(i, j) for j in range(i + 1, n)][:40]
@@ -480,6 +493,7 @@ def test_long_paired_kernel_at_the_edge_of_its_range():
         matrix[1] = matrix[20] = worst          # A/R, the two letters in use
         al = sa.Aligner(gap=-4, matrix=matrix, max_seq_len=400)
         al.upload(seqs)
+        al.set_cooperative(-1)
         assert any(it[5] != 0xFFFFFFFF for it in al.work_items(sa.TRIANGULAR, 0, n - 1).tolist()) == expect_pairs
         rec = al.align(sa.TRIANGULAR, 0, 6)
         _check_pairs(al, rec, _tri_pairs(n, 0, 6), gap=-4, matrix=matrix)
@@ -735,6 +749,7 @@ def test_random_tables_gaps_and_lengths(seed):
     seqs = ["".join(rng.choice(letters) for _ in range(rng.randint(lo, hi))) for _ in range(n)]
     al = sa.Aligner(gap=gap, matrix=matrix, max_seq_len=max(64, hi))
     al.upload(seqs)
+    al.set_cooperative(-1 if seed % 2 else 1)        # long cases: pair-per-lane kernels for odd seeds, wave-per-pair for even
     rec = al.align(sa.TRIANGULAR)
     pairs = _tri_pairs(n, 0, n - 1)
     assert len(rec) == len(pairs)
@@ -820,6 +835,36 @@ def test_library_names_the_kernel_it_ran():
     bl = sa.Aligner(max_seq_len=300)
     bl.upload(long_seqs)
     bl.align(sa.TRIANGULAR)
+    assert bl.last_kernel() == "sa_coop_kernel"          # 3160 pairs: fewer than 64 per CU
+    bl.set_cooperative(-1)
+    bl.align(sa.TRIANGULAR)
     assert bl.last_kernel() == "sa_long_pair_kernel<4>"
     bl.align(sa.ADJACENT)
     assert bl.last_kernel() == "sa_long_kernel<1, 2>"
+
+
+@pytest.mark.gpu
+def test_wave_per_pair_kernel_on_awkward_shapes():
+    """The wave-per-pair kernel against the pair-per-lane kernels (byte-identical records) and the checker: sequences
+    of 1 .. 64 residues next to long ones (one strip, first steps of a column, rows shorter than the wave), lengths
+    at the strip and block borders, two-letter sequences with long gap runs, an asymmetric table."""
+    rng = random.Random(23)
+    lens = [1, 2, 63, 64, 65, 127, 128, 129, 191, 192, 193, 15, 16, 17, 300, 1000, 999, 961, 3, 640]
+    seqs = ["".join(rng.choice(ALPHABET) for _ in range(n)) for n in lens]
+    seqs += ["".join(rng.choice("AW") for _ in range(rng.randint(1, 500))) for _ in range(25)]
+    seqs += ["A" * 700, "W" * 2, "AW" * 200]
+    matrix = [rng.randint(-6, 12) for _ in range(400)]
+    n = len(seqs)
+    for gap, mat in ((-4, None), (-2, matrix)):
+        al = sa.Aligner(gap=gap, matrix=mat, max_seq_len=1000)
+        al.upload(seqs)
+        al.set_cooperative(1)
+        tri = al.align(sa.TRIANGULAR)
+        adj = al.align(sa.ADJACENT)
+        assert al.last_kernel() == "sa_coop_kernel"
+        al.set_cooperative(-1)
+        assert np.array_equal(al.align(sa.TRIANGULAR), tri)
+        assert np.array_equal(al.align(sa.ADJACENT), adj)
+        assert al.last_kernel().startswith("sa_long_kernel")
+        _check_pairs(al, tri, _tri_pairs(n, 0, n - 1), gap=gap, matrix=mat)
+        _check_pairs(al, adj, [(k, k + 1) for k in range(n - 1)], gap=gap, matrix=mat)
