@@ -360,10 +360,13 @@ int build_items(sa_ctx* c, int schedule, uint64_t r0, uint64_t r1, std::vector<S
 uint32_t long_dir_rows(const sa_ctx* c) { return (c->max_seq + 7u) & ~7u; }
 
 // The wave-per-pair kernel (sa_kernels_coop.hip) takes a submission of long sequences when its pairs would fill only
-// a fraction of the chip's lanes on the pair-per-lane kernels: up to one wave's worth of pairs per CU.
+// a fraction of the chip's lanes on the pair-per-lane kernels.  Measured on proteins of 300-1000 residues, all-vs-all
+// (tools/coop_crossover.py): 16 471 pairs 4.4 ms against 22.9 ms, 65 341 pairs 16.8 against 23.5, 130 816 pairs 32.5
+// against 23.5 -- the pair-per-lane kernels take about 23 ms whatever the count until the chip is full, this one
+// 0.25 us per pair.  Up to 256 pairs per CU go here.
 bool use_coop(const sa_ctx* c, uint64_t npairs) {
     if (c->lslot <= SA_LP || c->coop_mode < 0 || npairs == 0) return false;
-    return c->coop_mode > 0 || npairs <= 64ull * (uint64_t)c->ncu;
+    return c->coop_mode > 0 || npairs <= 256ull * (uint64_t)c->ncu;
 }
 // its scratch per workgroup, KiB: direction blocks (strips x 16-step blocks x 256 B), two border columns, row notes
 uint32_t coop_kib_per_wg(const sa_ctx* c) {

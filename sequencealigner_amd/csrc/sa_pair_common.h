@@ -78,14 +78,27 @@
 // only place its result is used) behind a copy of the register it reads.
 typedef int sa_i32x4 __attribute__((ext_vector_type(4)));
 typedef int sa_i32x2 __attribute__((ext_vector_type(2)));
+// The table entries of group G + 1 are requested before group G is computed and awaited at the top of group G + 1
+// (two register sets take turns), so that the LDS latency -- 8 % of the launch when every group waited for its own
+// read -- is covered by a group's arithmetic.  Nothing is requested past the row's last group: a read still in
+// flight when the row function returns would land in registers the compiler has given to something else.
+// The requests and the wait are instructions the compiler cannot see through: the wait names the registers as its
+// outputs, so every use of them stays behind it.
+#define SA_PROF_REQUEST(LO, HI, G)                                                                                  \
+    asm volatile("ds_read_b64 %0, %2 offset:%3\n\tds_read_b64 %1, %2 offset:%4"                                       \
+                 : "=&v"(LO), "=&v"(HI) : "v"(row_lds), "n"(16 * (G)), "n"(16 * (G) + 8))
+#define SA_PROF_AWAIT(LO, HI) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(LO), "+v"(HI))
 #define SA_GROUP_PK(G)                                                                          \
     {                                                                                           \
         sa_i32x4 sc_;                                                                           \
-        {                                                                                       \
-            sa_i32x2 lo_, hi_;                                                                  \
-            asm volatile("ds_read_b64 %0, %2 offset:%3\n\tds_read_b64 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)" \
-                         : "=&v"(lo_), "=&v"(hi_) : "v"(row_lds), "n"(16 * (G)), "n"(16 * (G) + 8)); \
-            sc_.x = lo_.x; sc_.y = lo_.y; sc_.z = hi_.x; sc_.w = hi_.y;                         \
+        if (((G) & 1) == 0) {                                                                   \
+            SA_PROF_AWAIT(pa_lo, pa_hi);                                                        \
+            if ((G) + 1 < NG && gend != (G) + 1) SA_PROF_REQUEST(pb_lo, pb_hi, (G) + 1);        \
+            sc_.x = pa_lo.x; sc_.y = pa_lo.y; sc_.z = pa_hi.x; sc_.w = pa_hi.y;                 \
+        } else {                                                                                \
+            SA_PROF_AWAIT(pb_lo, pb_hi);                                                        \
+            if ((G) + 1 < NG && gend != (G) + 1) SA_PROF_REQUEST(pa_lo, pa_hi, (G) + 1);        \
+            sc_.x = pb_lo.x; sc_.y = pb_lo.y; sc_.z = pb_hi.x; sc_.w = pb_hi.y;                 \
         }                                                                                       \
         uint32_t mb0_ = B[4 * (G)] + (uint32_t)sc_.x;                                           \
         uint32_t ma1_ = B[4 * (G) + 1] + (uint32_t)sc_.y;                                       \
@@ -114,6 +127,8 @@ __device__ __forceinline__ void fill_row_pair(uint32_t (&B)[4 * NG], const int g
     // the lane's profile row as an LDS byte address: the four entries of a group come as two 8-byte reads (rows are
     // 2 banks apart modulo 64, see sa_device.h: 16-byte reads of rows 4 banks apart collide for residues b and b + 16)
     const uint32_t row_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const int32_t*)row_base;
+    sa_i32x2 pa_lo, pa_hi, pb_lo, pb_hi;
+    SA_PROF_REQUEST(pa_lo, pa_hi, 0);
     uint32_t ma_ = diag0 + (uint32_t)row_base[PS - 1];
     SA_GROUP_PK(0) SA_GROUP_PK(1) SA_GROUP_PK(2) SA_GROUP_PK(3) SA_GROUP_PK(4) SA_GROUP_PK(5) SA_GROUP_PK(6)
     SA_GROUP_PK(7) SA_GROUP_PK(8) SA_GROUP_PK(9) SA_GROUP_PK(10) SA_GROUP_PK(11) SA_GROUP_PK(12)
