@@ -99,11 +99,18 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_pair_kernel(const 
                     // packed query profile of columns 64s .. 64s+63 of the two first sequences
                     const int a1 = pseq[64 * s + lane], a2 = pseq[P.lslot + 64 * s + lane];
                     __syncthreads();
+                    // all forty table values are requested before the first is used (one round trip, not twenty)
+                    int t1[20], t2[20];
+#pragma unroll
+                    for (int b = 0; b < 20; b++) {
+                        t1[b] = P.sprime[a1 * SA_SPRIME_STRIDE + b];
+                        t2[b] = P.sprime[a2 * SA_SPRIME_STRIDE + b];
+                    }
 #pragma unroll
                     for (int b = 0; b < 20; b++) {
                         // padding scores 1 instead of 0 (an odd column's table entry must stay positive); padded
                         // cells lie to the right of and below every cell that is read
-                        const int s1 = max(P.sprime[a1 * SA_SPRIME_STRIDE + b], 1), s2 = max(P.sprime[a2 * SA_SPRIME_STRIDE + b], 1);
+                        const int s1 = max(t1[b], 1), s2 = max(t2[b], 1);
                         prof[b * SA_LONG_PAIR_PROF_STRIDE + SA_NB_PROF_INDEX(lane, SA_LONG_PAIR_PROF_STRIDE)] = (lane & 1) ? SA_NB_TABLE_B(s1) | (SA_NB_TABLE_B(s2) << 16)
                                                                      : SA_NB_TABLE_A(s1) | (SA_NB_TABLE_A(s2) << 16);
                     }
