@@ -87,6 +87,48 @@ def shard_for_rank(al, schedule, rank, world):
     return b[rank], b[rank + 1]
 
 
+def _dist():
+    import torch.distributed as dist
+    return dist if dist.is_available() and dist.is_initialized() else None
+
+
+def _on_device(t):
+    dist = _dist()
+    return t.cuda() if dist is not None and dist.get_backend() == "nccl" else t
+
+
+def reduce_max(x):
+    """Maximum of a float over the ranks (the value itself without a process group)."""
+    import torch
+    dist = _dist()
+    if dist is None:
+        return float(x)
+    t = _on_device(torch.tensor([x], dtype=torch.float64))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def reduce_sum(t):
+    """Element-wise sum of a tensor over the ranks, returned on the host."""
+    dist = _dist()
+    if dist is None:
+        return t
+    t = _on_device(t.clone())
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu()
+
+
+def per_rank(x):
+    """The ranks' values of a float, in rank order."""
+    import torch
+    dist = _dist()
+    if dist is None:
+        return [float(x)]
+    t = torch.zeros(dist.get_world_size(), dtype=torch.float64)
+    t[dist.get_rank()] = x
+    return [float(v) for v in reduce_sum(t)]
+
+
 def scratch_dir():
     return "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
 
@@ -328,20 +370,10 @@ def main():
     elapsed = time.perf_counter() - t0
     k_ms = sum(kernel_ms) / max(1, len(kernel_ms))
     kernel = al.last_kernel()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        tot = torch.tensor([float(my_pairs), float(my_cells)], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        total_pairs, total_cells = float(tot[0]), float(tot[1])
-        per = torch.zeros(world, dtype=torch.float64, device="cuda")
-        per[rank] = k_ms
-        dist.all_reduce(per, op=dist.ReduceOp.SUM)
-        per_rank_ms = [round(float(x), 3) for x in per.cpu()]
-    else:
-        total_pairs, total_cells = float(my_pairs), float(my_cells)
-        per_rank_ms = [round(k_ms, 3)]
+    elapsed = reduce_max(elapsed)
+    totals = reduce_sum(torch.tensor([float(my_pairs), float(my_cells)], dtype=torch.float64))
+    total_pairs, total_cells = float(totals[0]), float(totals[1])
+    per_rank_ms = [round(v, 3) for v in per_rank(k_ms)]
 
     if rank == 0:
         achieved = my_cells * OPS_PER_CELL / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0

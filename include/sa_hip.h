@@ -55,6 +55,7 @@ enum {
     SA_ERR_STATE = -5,        /* call out of order (nothing uploaded, nothing submitted, ...) */
     SA_ERR_BUSY = -6,         /* both in-flight slots are in use: call sa_next/sa_release first */
     SA_ERR_RECORD = -7,       /* record does not describe an alignment of the given sequences */
+    SA_ERR_KERNEL = -9,       /* a kernel found its launch configuration unusable and did nothing (reported by sa_next* / sa_run_resident) */
     SA_ERR_NOALLOC_SIZE = -8, /* sa_align_adjacent_noalloc: more pairs than its fixed scratch buffer serves */
     SA_ERR_HIP = -1000        /* -1000 - hipError_t */
 };
@@ -161,7 +162,7 @@ int sa_set_tuning(sa_ctx* ctx, uint32_t tiles_per_item, uint32_t wg_per_cu);
 /* width of the TRIANGULAR length buckets in residues (a wave's 64 second sequences, and the two first sequences of a
  * packed wave, come from one bucket: wide buckets pad short sequences up to the longest of the wave, narrow ones leave
  * first sequences without a partner); 0 = automatic: exact lengths when every length has 256 sequences or more, wider
- * otherwise.  Results do not depend on it. */
+ * otherwise (sequences longer than 64 residues: about 48 sequences per bucket, 8 to 64 residues wide).  Results do not depend on it. */
 int sa_set_bucket_width(sa_ctx* ctx, uint32_t width);
 /* TRIANGULAR work normally runs on kernels that handle two first sequences per wave in packed
  * 16-bit cells; they are used only when the substitution table allows it (S - 2*gap >= 1 everywhere

@@ -106,6 +106,7 @@ struct Work {                 // one submitted (or prepared) row range
     DevBuf lens, offs, text, total, scan_tmp;
     PinBuf host_total;
     PinBuf items_pin;          // the work list on its way to the device (pinned: the copy needs no wait)
+    PinBuf status_pin;         // the kernels' status word, copied back behind every launch
     bool text_mode = false;
 };
 
@@ -203,6 +204,10 @@ int ensure_triangular(sa_ctx* c) {
     const uint32_t range = c->max_seq - c->min_seq + 1;
     uint32_t width = (uint32_t)((256ull * range + n - 1) / n);
     width = std::max(1u, std::min(width, 64u));
+    // long sequences: about 48 sequences per bucket, at least 8 residues wide (2 000 proteins of 300-1000 residues: 97.2 ms
+    // at 16 residues against 100.8 at 64; 10 000: flat between 8 and 18) -- a wave's rows run to its longest second
+    // sequence, and a wave takes its 64 lanes across bucket borders anyway
+    if (c->lslot > SA_LP) width = std::max(8u, std::min((uint32_t)((48ull * range + n - 1) / n), 64u));
     if (c->bucket_width_forced) width = std::max(1u, std::min(c->bucket_width_forced, std::max(range, 1u)));
     const uint32_t nb = (range + width - 1) / width;
     if ((uint64_t)nb * n > (1ull << 28)) return SA_ERR_NOMEM;   // cursor table of more than 1 GiB
@@ -489,7 +494,15 @@ int launch_work(sa_ctx* c, Work& w, bool timed) {
     }
     SA_HIP_TRY(hipGetLastError());
     if (timed) SA_HIP_TRY(hipEventRecord(w.t1, c->compute));
+    if ((rc = w.status_pin.reserve(16))) return rc;
+    SA_HIP_TRY(hipMemcpyAsync(w.status_pin.p, (const uint32_t*)w.counter.p + SA_STATUS_WORD, 4, hipMemcpyDeviceToHost, c->compute));
     return SA_OK;
+}
+
+// after the launch's stream work is complete: did a kernel refuse to run?
+int launch_status(const Work& w) {
+    if (w.npairs == 0 || w.nitems == 0 || !w.status_pin.p) return SA_OK;
+    return *(const uint32_t*)w.status_pin.p ? SA_ERR_KERNEL : SA_OK;
 }
 
 int prepare_work(sa_ctx* c, Work& w, int schedule, uint64_t r0, uint64_t r1, bool need_host) {
@@ -550,7 +563,7 @@ int init_events(Work& w) {
 void free_work(Work& w) {
     w.items.release(); w.out.release(); w.counter.release(); w.host.release();
     w.lens.release(); w.offs.release(); w.text.release(); w.total.release(); w.scan_tmp.release();
-    w.host_total.release(); w.items_pin.release();
+    w.host_total.release(); w.items_pin.release(); w.status_pin.release();
     if (w.kernel_done) (void)hipEventDestroy(w.kernel_done);
     if (w.copied) (void)hipEventDestroy(w.copied);
     if (w.t0) (void)hipEventDestroy(w.t0);
@@ -575,6 +588,7 @@ const char* sa_strerror(int code) {
         case SA_ERR_STATE: return "call out of order";
         case SA_ERR_BUSY: return "two submissions already in flight";
         case SA_ERR_RECORD: return "record does not match the sequences";
+        case SA_ERR_KERNEL: return "a kernel refused its launch configuration (dynamic LDS not at offset 0)";
         case SA_ERR_NOALLOC_SIZE: return "more pairs than the fixed scratch buffer of sa_align_adjacent_noalloc serves";
         default: break;
     }
@@ -922,6 +936,7 @@ int sa_next(sa_ctx* c, const uint8_t** records, uint64_t* first_pair, uint64_t* 
     if (w.text_mode) return SA_ERR_STATE;
     SA_HIP_TRY(hipSetDevice(c->device));
     SA_HIP_TRY(hipEventSynchronize(w.copied));
+    if (int st = launch_status(w)) return st;
     *records = (const uint8_t*)w.host.p;
     *first_pair = w.first_pair;
     *npairs = w.npairs;
@@ -1055,6 +1070,7 @@ int sa_next_text(sa_ctx* c, const char** text, uint64_t* nbytes, uint64_t* first
     if (!w.text_mode) return SA_ERR_STATE;
     SA_HIP_TRY(hipSetDevice(c->device));
     SA_HIP_TRY(hipEventSynchronize(w.kernel_done));
+    if (int st = launch_status(w)) return st;
     uint64_t total = 0;
     if (w.npairs) {
         total = *(const uint64_t*)w.host_total.p;
@@ -1093,6 +1109,7 @@ int sa_run_resident(sa_ctx* c, float* kernel_ms) {
     int rc = launch_work(c, c->resident, true);
     if (rc) return rc;
     SA_HIP_TRY(hipStreamSynchronize(c->compute));
+    if (int st = launch_status(c->resident)) return st;
     if (kernel_ms) {
         *kernel_ms = 0.f;
         if (c->resident.npairs && c->resident.nitems)

@@ -23,6 +23,9 @@
 #define SA_LP 64                 /* DP columns held in registers by the peptide kernel */
 #define SA_PAD_CODE 20           /* residue code of padding; its substitution scores are 0 */
 #define SA_INVALID_FI 0xFFFFFFFFu
+/* the 256-byte buffer of the work-queue head: dword 0 = head, dword SA_STATUS_WORD = status bits a kernel may raise */
+#define SA_STATUS_WORD 8
+#define SA_STATUS_LDS_BASE 1u    /* the kernel's dynamic LDS does not start at offset 0: it refused to run */
 #define SA_SPRIME_STRIDE 32      /* dwords per row of the shifted substitution table */
 
 /* LDS carve-up of the peptide kernel (bytes) */

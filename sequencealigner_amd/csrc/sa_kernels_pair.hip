@@ -34,8 +34,13 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
     uint8_t* const pcol = smem + PROF_BYTES;
     uint32_t* const stage = reinterpret_cast<uint32_t*>(smem + PROF_BYTES + 2 * SA_LDS_EMASK_BYTES);
     const int lane = threadIdx.x;
-    // the traceback addresses pcol by its offset inside the workgroup's LDS: the dynamic area starts at 0
-    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t*)smem != 0u) __builtin_trap();
+    // The traceback addresses pcol by its offset inside the workgroup's LDS, a constant folded into the instruction: the
+    // dynamic area must start at 0 (it does: the kernel has no other LDS object).  Should a toolchain ever place it
+    // elsewhere, the launch reports it through the status word behind the queue head and does nothing; every wave leaves.
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t*)smem != 0u) {
+        if (lane == 0) atomicOr(P.counter + SA_STATUS_WORD, SA_STATUS_LDS_BASE);
+        return;
+    }
     // rows 0..63 of the spill area hold the direction rows of the low halves, rows 64..127 those of the high halves
     const __amdgpu_buffer_rsrc_t spill = __builtin_amdgcn_make_buffer_rsrc(
         P.spill + (size_t)blockIdx.x * P.spill_rows * 256, 0, P.spill_rows * 1024, SA_BUFFER_FLAGS);

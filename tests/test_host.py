@@ -374,3 +374,15 @@ def test_scoring_matrix_file_loader(tmp_path):
     st.scoring_matrix_file = str(short).encode()
     rc, text = sa.validate_settings(st)
     assert rc != 0 and "399" in text
+
+
+def test_bench_refuses_more_gpus_than_there_are():
+    """`bench.py --gpus N` outside a torchrun environment starts its ranks itself, or says why it cannot: it must
+    not measure one GPU and report it as N."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64"], env=env, capture_output=True,
+                         text=True, timeout=200)
+    assert out.returncode != 0 and "--gpus 64" in out.stderr and out.stdout.strip() == ""
