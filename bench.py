@@ -340,9 +340,13 @@ def main():
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
         sys.exit(2)
+    # Rehearsal knobs for a box with fewer GPUs than ranks (the N > 1 code path on one card): SA_BENCH_DEVICE pins every
+    # rank to one device, SA_BENCH_BACKEND=gloo replaces RCCL, which refuses two ranks on one GPU.
+    if "SA_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["SA_BENCH_DEVICE"])
     if world > 1:
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl")
+        dist.init_process_group(os.environ.get("SA_BENCH_BACKEND", "nccl"))
 
     def barrier_sync():
         if world > 1:
