@@ -31,6 +31,7 @@
 // sa_device.h, byte-identical to those of sa_long_kernel.
 #include "sa_kernel_common.h"
 
+#define SA_COOP_AHEAD 3                     /* steps between the request of a table entry and its use */
 #define SA_COOP_NEG_CODE 21                 /* row residue of the rows above the matrix */
 #define SA_COOP_DPP_WAVE_SHR1 0x138         /* DPP control: lane l reads lane l-1 across the whole wave */
 
@@ -107,10 +108,21 @@ __global__ void __launch_bounds__(64, 4) sa_coop_kernel(const SaPepParams P) {
             int b = lane == 0 ? (int)seq2[0] : SA_COOP_NEG_CODE;
             uint32_t acc = 0;
             int colbuf = 0;
+            // Table entries are requested SA_COOP_AHEAD steps before they are used: the row residues travel along the
+            // lanes independently of the cells, so their wave runs ahead of the cells' and the LDS latency (several
+            // steps of arithmetic with one wave per SIMD, the regime this kernel is for) stays covered.
+            // b = travelling residues of step t + AHEAD; Tq[k] = table entry of step t + k.
+            int Tq[SA_COOP_AHEAD];
+#pragma unroll
+            for (int k = 0; k < SA_COOP_AHEAD; k++) {
+                Tq[k] = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(tab) + a32 + b * 4);
+                b = sa_wave_shr1((int)seq2[k + 1], b);
+            }
             for (int sb = 0; sb < nsuper; sb++) {
                 // rows 64 sb + 1 .. 64 sb + 64 for lane 0's next steps: residues and the border column
                 const int rown = 64 * sb + 1 + lane;
-                const int resin = rown < (int)lslot ? (int)seq2[rown] : SA_PAD_CODE;
+                const int rres = rown + SA_COOP_AHEAD;           // the residues run ahead of the cells
+                const int resin = rres < (int)lslot ? (int)seq2[rres] : SA_PAD_CODE;
                 const int colin = first_strip ? 0 : bin[rown];
 #pragma unroll
                 for (int blk = 0; blk < 4; blk++) {
@@ -118,7 +130,12 @@ __global__ void __launch_bounds__(64, 4) sa_coop_kernel(const SaPepParams P) {
                     for (int u = 0; u < 16; u++) {
                         const int t = 64 * sb + 16 * blk + u;
                         const int tl = 16 * blk + u;                     // t mod 64, a constant after unrolling
-                        const int T = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(tab) + a32 + b * 4);
+                        const int T = Tq[0];
+#pragma unroll
+                        for (int k = 0; k + 1 < SA_COOP_AHEAD; k++) Tq[k] = Tq[k + 1];
+                        Tq[SA_COOP_AHEAD - 1] = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(tab) + a32 + b * 4);
+                        // the residues of the step after: from the lane on the left, lane 0 takes the next residue
+                        b = sa_wave_shr1(__builtin_amdgcn_readlane(resin, tl), b);
                         const int m = left_prev + T;
                         const int h = max3i(m, up, left);
                         acc = __builtin_amdgcn_alignbit((uint32_t)h, acc, 2);
@@ -129,12 +146,9 @@ __global__ void __launch_bounds__(64, 4) sa_coop_kernel(const SaPepParams P) {
                         const int last = __builtin_amdgcn_readlane(zl, 63);
                         colbuf = sa_writelane_step(last, tl, colbuf);
                         if (t == tstar && s == nstrips - 1) dfinal = __builtin_amdgcn_readlane(zl, lstar) >> 2;
-                        // next step's LEFT and row residue come from the lane on the left; lane 0 takes the border
-                        // column's next row and the next residue
+                        // next step's LEFT comes from the lane on the left; lane 0 takes the border column's next row
                         const int nb = __builtin_amdgcn_readlane(colin, tl);
-                        const int nr = __builtin_amdgcn_readlane(resin, tl);
                         left = sa_wave_shr1(nb, zl);
-                        b = sa_wave_shr1(nr, b);
                     }
                     dirs[((size_t)s * blocks_cap + 4 * sb + blk) * 64 + lane] = acc;
                 }
