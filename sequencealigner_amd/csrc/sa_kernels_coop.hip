@@ -14,9 +14,10 @@
 //    before -- a second DPP shift, lane 0 taking the next residue.  The substitution score is one LDS
 //    read of the table S' indexed by the lane's column residue and the travelling row residue.
 //    Cells are the tagged 32-bit cells of sa_kernel_common.h (4 D + tag, DIAG 3 > UP 1 > LEFT 0 decided by
-//    the three-way maximum itself).  Rows above the matrix are fed a residue code whose score is
-//    hugely negative: by induction those cells stay at the border value D = 0, so a lane needs no test
-//    for "has my column started".  The last column of a strip is collected lane by lane
+//    the three-way maximum itself).  Rows above and below the matrix are fed a residue code whose score is
+//    hugely negative: above, those cells stay at the border value D = 0 by induction, so a lane needs no
+//    test for "has my column started"; below, a column keeps the value of the matrix's last row (UP wins:
+//    D never decreases along a row), so the score is read from lane (len1 - 1) mod 64 after the last strip.  The last column of a strip is collected lane by lane
 //    (v_readlane + v_writelane) and handed to the next strip as its left border, 64 rows at a time.
 //  * directions: every lane shifts its cell's tag into a dword, 16 steps per dword, and the wave stores
 //    the 64 dwords of a 16-step block with one coalesced 256-byte store.  The tag of cell (r, c) is at
@@ -40,15 +41,11 @@ __device__ __forceinline__ int sa_wave_shr1(int old_for_lane0, int v) {
     return __builtin_amdgcn_update_dpp(old_for_lane0, v, SA_COOP_DPP_WAVE_SHR1, 0xf, 0xf, false);
 }
 
-// v_writelane_b32: one lane of `dst` takes a wave-uniform value.  Value and lane index are both scalars, and a vector
-// instruction of this generation reads one scalar register only: the lane index goes through M0 (one wait state
-// after the scalar move).  When the index was computed from v_readlane results (the walk), the move itself must
-// come four wait states after them.
-__device__ __forceinline__ int sa_writelane_step(int value, int lane_index, int dst) {
-    value = __builtin_amdgcn_readfirstlane(value);
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(dst) : "s"(value), "s"(lane_index));  /* M0 is otherwise unused in this kernel */
-    return dst;
-}
+// v_writelane_b32: one lane of `dst` takes a wave-uniform value.  In the fill the lane index is a literal.  In the
+// walk value and lane index are both scalars, and a vector instruction of this generation reads one scalar register
+// only: the lane index goes through M0 (one wait state after the scalar move), and as it was computed from v_readlane
+// results the move itself must come four wait states after them.
+#define SA_WRITELANE_CONST(DST, VALUE, LANE) asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(DST) : "s"(VALUE), "n"(LANE))
 __device__ __forceinline__ uint32_t sa_writelane(int value, int lane_index, uint32_t dst) {
     value = __builtin_amdgcn_readfirstlane(value);
     lane_index = __builtin_amdgcn_readfirstlane(lane_index);
@@ -92,7 +89,7 @@ __global__ void __launch_bounds__(64, 4) sa_coop_kernel(const SaPepParams P) {
         uint8_t* const rec = P.out + (((uint64_t)item.c0 << 32) | item.b0) * P.stride;
         const int nstrips = (len1 + 63) >> 6;
         const int nsuper = (len2 + 63 + 63) >> 6;          // 64-step super-blocks of a strip: steps 0 .. len2 + 62
-        const int lstar = (len1 - 1) & 63, tstar = len2 - 1 + lstar;
+        const int lstar = (len1 - 1) & 63;
         int dfinal = 0;
 
         // ------------------------------------------------------------------ fill
@@ -116,48 +113,54 @@ __global__ void __launch_bounds__(64, 4) sa_coop_kernel(const SaPepParams P) {
 #pragma unroll
             for (int k = 0; k < SA_COOP_AHEAD; k++) {
                 Tq[k] = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(tab) + a32 + b * 4);
-                b = sa_wave_shr1((int)seq2[k + 1], b);
+                b = sa_wave_shr1(k + 1 < len2 ? (int)seq2[k + 1] : SA_COOP_NEG_CODE, b);
             }
             for (int sb = 0; sb < nsuper; sb++) {
                 // rows 64 sb + 1 .. 64 sb + 64 for lane 0's next steps: residues and the border column
                 const int rown = 64 * sb + 1 + lane;
                 const int rres = rown + SA_COOP_AHEAD;           // the residues run ahead of the cells
-                const int resin = rres < (int)lslot ? (int)seq2[rres] : SA_PAD_CODE;
-                const int colin = first_strip ? 0 : bin[rown];
-#pragma unroll
-                for (int blk = 0; blk < 4; blk++) {
-#pragma unroll
-                    for (int u = 0; u < 16; u++) {
-                        const int t = 64 * sb + 16 * blk + u;
-                        const int tl = 16 * blk + u;                     // t mod 64, a constant after unrolling
-                        const int T = Tq[0];
-#pragma unroll
-                        for (int k = 0; k + 1 < SA_COOP_AHEAD; k++) Tq[k] = Tq[k + 1];
-                        Tq[SA_COOP_AHEAD - 1] = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(tab) + a32 + b * 4);
-                        // the residues of the step after: from the lane on the left, lane 0 takes the next residue
-                        b = sa_wave_shr1(__builtin_amdgcn_readlane(resin, tl), b);
-                        const int m = left_prev + T;
-                        const int h = max3i(m, up, left);
-                        acc = __builtin_amdgcn_alignbit((uint32_t)h, acc, 2);
-                        const int zl = h & ~3;
-                        up = zl | 1;
-                        left_prev = left;
-                        // the strip's last column, row t - 63, for the next strip
-                        const int last = __builtin_amdgcn_readlane(zl, 63);
-                        colbuf = sa_writelane_step(last, tl, colbuf);
-                        if (t == tstar && s == nstrips - 1) dfinal = __builtin_amdgcn_readlane(zl, lstar) >> 2;
-                        // next step's LEFT comes from the lane on the left; lane 0 takes the border column's next row
-                        const int nb = __builtin_amdgcn_readlane(colin, tl);
-                        left = sa_wave_shr1(nb, zl);
-                    }
-                    dirs[((size_t)s * blocks_cap + 4 * sb + blk) * 64 + lane] = acc;
-                }
+                const int resin = rres < len2 ? (int)seq2[rres] : SA_COOP_NEG_CODE;      // below the matrix as above it
+                // below the matrix the border is 0 (what the buffer holds there is stale, and a LEFT operand above the
+                // frozen column value would thaw it)
+                const int colin = (first_strip || rown >= len2) ? 0 : bin[rown];
+                // One step; TL = t mod 64 is a literal, so that lane indices are immediates.
+#define SA_COOP_STEP(TL)                                                                                              \
+    {                                                                                                                 \
+        const int T = Tq[0];                                                                                          \
+        _Pragma("unroll") for (int k = 0; k + 1 < SA_COOP_AHEAD; k++) Tq[k] = Tq[k + 1];                              \
+        Tq[SA_COOP_AHEAD - 1] = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(tab) + a32 + b * 4);  \
+        /* the residues of the step after: from the lane on the left, lane 0 takes the next residue */               \
+        b = sa_wave_shr1(__builtin_amdgcn_readlane(resin, (TL)), b);                                                  \
+        const int m = left_prev + T;                                                                                  \
+        const int h = max3i(m, up, left);                                                                             \
+        acc = __builtin_amdgcn_alignbit((uint32_t)h, acc, 2);                                                         \
+        const int zl = h & ~3;                                                                                        \
+        up = zl | 1;                                                                                                  \
+        left_prev = left;                                                                                             \
+        /* the strip's last column, row t - 63, for the next strip */                                                 \
+        const int last = __builtin_amdgcn_readlane(zl, 63);                                                           \
+        SA_WRITELANE_CONST(colbuf, last, (TL));                                                                       \
+        /* next step's LEFT comes from the lane on the left; lane 0 takes the border column's next row */             \
+        left = sa_wave_shr1(__builtin_amdgcn_readlane(colin, (TL)), zl);                                              \
+    }
+#define SA_COOP_BLOCK(B)                                                                                              \
+    SA_COOP_STEP(16 * (B) + 0) SA_COOP_STEP(16 * (B) + 1) SA_COOP_STEP(16 * (B) + 2) SA_COOP_STEP(16 * (B) + 3)       \
+    SA_COOP_STEP(16 * (B) + 4) SA_COOP_STEP(16 * (B) + 5) SA_COOP_STEP(16 * (B) + 6) SA_COOP_STEP(16 * (B) + 7)       \
+    SA_COOP_STEP(16 * (B) + 8) SA_COOP_STEP(16 * (B) + 9) SA_COOP_STEP(16 * (B) + 10) SA_COOP_STEP(16 * (B) + 11)     \
+    SA_COOP_STEP(16 * (B) + 12) SA_COOP_STEP(16 * (B) + 13) SA_COOP_STEP(16 * (B) + 14) SA_COOP_STEP(16 * (B) + 15)   \
+    dirs[((size_t)s * blocks_cap + 4 * sb + (B)) * 64 + lane] = acc;
+                SA_COOP_BLOCK(0) SA_COOP_BLOCK(1) SA_COOP_BLOCK(2) SA_COOP_BLOCK(3)
+#undef SA_COOP_BLOCK
+#undef SA_COOP_STEP
                 // colbuf lane i = last column of row 64 sb + i - 63
                 if (more) {
                     const int r = 64 * sb + lane - 63;
                     if (r >= 0) bout[r] = colbuf;
                 }
             }
+            // rows below the matrix score like the rows above it: every lane's UP value has stayed what it was in the
+            // matrix's last row (D never decreases along a row, so LEFT cannot pass it)
+            if (s == nstrips - 1) dfinal = __builtin_amdgcn_readlane(up, lstar) >> 2;
             __syncthreads();      // border column and direction blocks are complete before anyone reads them
         }
 
