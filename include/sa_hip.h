@@ -169,7 +169,7 @@ int sa_set_bucket_width(sa_ctx* ctx, uint32_t width);
  * and longest sequence * max(S - 2*gap) <= 1983 when no sequence exceeds 64 residues; 1 .. 24 otherwise).  enable = 0 forces one first
  * sequence per wave, 32-bit cells (same results; for comparisons and tests).  Default: enabled. */
 int sa_set_pairing(sa_ctx* ctx, int enable);
-/* Sequences longer than 64 residues, few pairs: a submission of at most 256 pairs per CU runs on a kernel that gives
+/* Sequences longer than 64 residues, few pairs: a submission of at most 384 pairs per CU runs on a kernel that gives
  * every pair a whole wave (the 64 lanes sweep anti-diagonals of one matrix and hand their operands to the neighbour
  * lane) instead of a lane: a few hundred protein pairs then use a few hundred waves, not a handful.  The reference
  * handles one pair per call of align_sequences (include/seqalign.h:13-113) whatever the count.  mode 0 (default)

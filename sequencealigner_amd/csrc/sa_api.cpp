@@ -366,12 +366,12 @@ uint32_t long_dir_rows(const sa_ctx* c) { return (c->max_seq + 7u) & ~7u; }
 
 // The wave-per-pair kernel (sa_kernels_coop.hip) takes a submission of long sequences when its pairs would fill only
 // a fraction of the chip's lanes on the pair-per-lane kernels.  Measured on proteins of 300-1000 residues, all-vs-all
-// (tools/coop_crossover.py): 16 471 pairs 4.4 ms against 22.9 ms, 65 341 pairs 16.8 against 23.5, 130 816 pairs 32.5
-// against 23.5 -- the pair-per-lane kernels take about 23 ms whatever the count until the chip is full, this one
-// 0.25 us per pair.  Up to 256 pairs per CU go here.
+// (tools/coop_crossover.py): 16 471 pairs 3.4 ms against 21.4 ms, 65 341 pairs 12.6 against 22.1, 130 816 pairs 24.3
+// against 22.6 -- the pair-per-lane kernels take about 22 ms whatever the count until the chip is full, this one
+// 0.19 us per pair.  Up to 384 pairs per CU go here.
 bool use_coop(const sa_ctx* c, uint64_t npairs) {
     if (c->lslot <= SA_LP || c->coop_mode < 0 || npairs == 0) return false;
-    return c->coop_mode > 0 || npairs <= 256ull * (uint64_t)c->ncu;
+    return c->coop_mode > 0 || npairs <= 384ull * (uint64_t)c->ncu;
 }
 // its scratch per workgroup, KiB: direction blocks (strips x 16-step blocks x 256 B), two border columns, row notes
 uint32_t coop_kib_per_wg(const sa_ctx* c) {

@@ -835,7 +835,7 @@ def test_library_names_the_kernel_it_ran():
     bl = sa.Aligner(max_seq_len=300)
     bl.upload(long_seqs)
     bl.align(sa.TRIANGULAR)
-    assert bl.last_kernel() == "sa_coop_kernel"          # 3160 pairs: fewer than 256 per CU
+    assert bl.last_kernel() == "sa_coop_kernel"          # 3160 pairs: fewer than 384 per CU
     bl.set_cooperative(-1)
     bl.align(sa.TRIANGULAR)
     assert bl.last_kernel() == "sa_long_pair_kernel<4>"
