@@ -52,6 +52,7 @@ MEGA_CELLS = 2214981084
 WORKLOADS = {
     # name: (n, lo, hi, seed, description)
     "peptides50k": (50000, 6, 50, 1, "synthetic 50k peptides len 6-50 seed 1, all-vs-all (BASELINE.json configs[2])"),
+    "peptides_g7": (50000, 25, 28, 1, "synthetic 50k peptides len 25-28 seed 1, all-vs-all (experiment: one row shape)"),
     "peptides20k": (20000, 6, 50, 1, "synthetic 20k peptides len 6-50 seed 1, all-vs-all"),
     "peptides4k": (4000, 6, 50, 1, "synthetic 4k peptides len 6-50 seed 1, all-vs-all"),
     "proteins10k": (10000, 300, 1000, 2, "synthetic 10k proteins len 300-1000 seed 2, all-vs-all (BASELINE.json configs[4])"),

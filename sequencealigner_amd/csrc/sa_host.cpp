@@ -679,7 +679,8 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
                     continue;
                 }
                 if (st->mode_write && np) {
-                    join_writer();          // one writer per device at a time: its buffer set is the other one
+                    // the previous chunk's writer works on the other buffer set: it is joined only when this chunk's
+                    // rows are ready, so writing overlaps formatting
                     std::vector<std::vector<char>>& bufs = bufset[cur_set];
                     std::vector<size_t>& used = usedset[cur_set];
                     std::atomic<int> bad(0);
@@ -722,6 +723,7 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
                     uint64_t total_bytes = 0;
                     for (int t = 0; t < fthreads; t++) total_bytes += used[(size_t)t];
                     publish(k, total_bytes);
+                    join_writer();
                     // every format slice goes to its own place in the file, all slices at once
                     writer = std::thread([&, k, total_bytes, cur_set]() {
                         uint64_t chunk_off = 0;

@@ -83,7 +83,6 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
         uint8_t* const out_row1 = P.out + ((uint64_t)p1 * (2 * n - p1 - 1) / 2 - P.out_base_pair) * P.stride;
         uint8_t* const out_row2 = has2 ? P.out + ((uint64_t)p2 * (2 * n - p2 - 1) / 2 - P.out_base_pair) * P.stride : out_row1;
         const int gend = (max(lenp1, lenp2) + 3) >> 2;
-        const int wpr = (gend + 3) >> 2;                // dwords per direction row, lane and pair
         SA_PHASE(1);
 
         for (uint32_t task = 0; task < item.count; task++) {
@@ -133,60 +132,84 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
                     dst[2 * q4 + 1] = make_uint2(v.z, v.w);
                 }
             }
-            const int dir_lane = lane * wpr * 4;      // byte offset of this lane inside a direction row
-            const int half_off = SA_LP * 256 * wpr;   // byte offset of the high halves' rows
-            // direction row of one pair: dword k = columns 16k .. 16k+15, column 16k+i at bits 2(15-i)
-            auto store_dirs = [&](int r, int g) {
-                const int wr = (g + 3) >> 2;
-                const int row_off = r * 256 * wpr;
+            // Direction rows, one pair at a time: 16-bit pieces of eight columns, n16 per row and lane; the rows of the
+            // low halves first, then those of the high halves (layout and register form: traceback_pk).
+            const int n16 = (gend + 1) >> 1;
+            const int row_bytes = 128 * n16;
+            const int half_off = SA_LP * row_bytes;
+            // GEND = the row's length in groups as a constant: what is stored, and how, is then decided at compile time
+            auto store_dirs = [&](int r, auto GC) {
+                constexpr int GEND = decltype(GC)::value;
+                constexpr int N16 = (GEND + 1) / 2, WD = N16 / 2, ODD = N16 & 1;
+                const int dir_lane = lane * (WD * 4);
+                const int row_off = r * (128 * N16);
+                const int hoff = SA_LP * (128 * N16) + row_off;
                 uint32_t lo[4], hi[4];
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    const uint32_t w0 = (2 * k < NACC) ? e[(2 * k < NACC) ? 2 * k : 0] : 0;
-                    const uint32_t w1 = (2 * k + 1 < NACC) ? e[(2 * k + 1 < NACC) ? 2 * k + 1 : 0] : 0;
-                    lo[k] = __builtin_amdgcn_perm(w0, w1, 0x05040100u);     // low halves:  w0.lo : w1.lo
-                    hi[k] = __builtin_amdgcn_perm(w0, w1, 0x07060302u);     // high halves: w0.hi : w1.hi
+                    if (k < WD) {
+                        const uint32_t w0 = e[2 * k < NACC ? 2 * k : 0], w1 = e[2 * k + 1 < NACC ? 2 * k + 1 : 0];
+                        lo[k] = __builtin_amdgcn_perm(w0, w1, 0x05040100u);     // low halves:  w0.lo : w1.lo
+                        hi[k] = __builtin_amdgcn_perm(w0, w1, 0x07060302u);     // high halves: w0.hi : w1.hi
+                    } else {
+                        lo[k] = hi[k] = 0;
+                    }
                 }
                 // last dword first (see traceback_pk)
-                if (wr == 4) {
+                if constexpr (WD == 4) {
                     const sa_u32x4 a = {lo[3], lo[2], lo[1], lo[0]}, b = {hi[3], hi[2], hi[1], hi[0]};
                     __builtin_amdgcn_raw_buffer_store_b128(a, spill, dir_lane, row_off, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(b, spill, dir_lane, half_off + row_off, 0);
-                } else if (wr == 3) {
+                    __builtin_amdgcn_raw_buffer_store_b128(b, spill, dir_lane, hoff, 0);
+                } else if constexpr (WD == 3) {
                     const sa_u32x3 a = {lo[2], lo[1], lo[0]}, b = {hi[2], hi[1], hi[0]};
                     __builtin_amdgcn_raw_buffer_store_b96(a, spill, dir_lane, row_off, 0);
-                    __builtin_amdgcn_raw_buffer_store_b96(b, spill, dir_lane, half_off + row_off, 0);
-                } else if (wr == 2) {
+                    __builtin_amdgcn_raw_buffer_store_b96(b, spill, dir_lane, hoff, 0);
+                } else if constexpr (WD == 2) {
                     const sa_u32x2 a = {lo[1], lo[0]}, b = {hi[1], hi[0]};
                     __builtin_amdgcn_raw_buffer_store_b64(a, spill, dir_lane, row_off, 0);
-                    __builtin_amdgcn_raw_buffer_store_b64(b, spill, dir_lane, half_off + row_off, 0);
-                } else {
+                    __builtin_amdgcn_raw_buffer_store_b64(b, spill, dir_lane, hoff, 0);
+                } else if constexpr (WD == 1) {
                     __builtin_amdgcn_raw_buffer_store_b32(lo[0], spill, dir_lane, row_off, 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(hi[0], spill, dir_lane, half_off + row_off, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(hi[0], spill, dir_lane, hoff, 0);
+                }
+                if constexpr (ODD == 1) {
+                    // the row's last eight columns: the word's two halves are the two pairs' pieces as they stand
+                    const uint32_t w = e[2 * WD < NACC ? 2 * WD : 0];
+                    const int piece_lane = 256 * WD + lane * 2;
+                    __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(w & 0xffffu), spill, piece_lane, row_off, 0);
+                    __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(w >> 16), spill, piece_lane, hoff, 0);
                 }
             };
 
-            // profile row (as a dword offset) of the row to come
-            uint32_t o0 = qres[0] * PS;
             uint32_t dfin1 = 0, dfin2 = 0;       // bank values of the last cells of the two matrices
-            for (int r = 0; r < maxlen; r++) {
-                const uint32_t b1 = qres[min(r + 1, SA_LP - 1)];
-                // the row's end tests compare this copy of gend where they stand: hoisted out of the loop they
-                // would each hold a pair of scalar registers, more than there are
-                int gr = gend;
-                asm volatile("" : "+s"(gr));
-                // Every lane computes and stores every row, also lanes whose sequence 2 has ended (padding
-                // residues; those rows are never read): with the row under a per-lane condition the compiler
-                // keeps a second copy of the register row for the lanes that skip it.  A lane takes its
-                // scores when its last row is done.
-                fill_row_pair<NG, PS>(R, gr, SA_NB_UP_B, 0u, prof + o0, e);
-                store_dirs(r, gr);
-                if (r + 1 == lenq) {
-                    dfin1 = pick_packed<NC>(R, lenp1 - 1);
-                    dfin2 = pick_packed<NC>(R, max(lenp2, 1) - 1);
+            // The row loop, once per row length: with the number of groups a constant the row is straight-line code
+            // (no compare and branch per group, no test before a table request) and the shape of the direction stores
+            // is fixed.  Items come sorted by length, so the waves of a CU run the same copy most of the time.
+            auto fill_rows = [&](auto GC) {
+                constexpr int GEND = decltype(GC)::value;
+                uint32_t o0 = qres[0] * PS;      // profile row (as a dword offset) of the row to come
+                for (int r = 0; r < maxlen; r++) {
+                    const uint32_t b1 = qres[min(r + 1, SA_LP - 1)];
+                    // Every lane computes and stores every row, also lanes whose sequence 2 has ended (padding
+                    // residues; those rows are never read): with the row under a per-lane condition the compiler
+                    // keeps a second copy of the register row for the lanes that skip it.  A lane takes its
+                    // scores when its last row is done.
+                    fill_row_pair<NG, PS, GEND>(R, GEND, SA_NB_UP_B, 0u, prof + o0, e);
+                    store_dirs(r, GC);
+                    if (r + 1 == lenq) {
+                        dfin1 = pick_packed<NC>(R, lenp1 - 1);
+                        dfin2 = pick_packed<NC>(R, max(lenp2, 1) - 1);
+                    }
+                    o0 = b1 * PS;
                 }
-                o0 = b1 * PS;
+            };
+#define SA_ROWS(G) case G: if constexpr ((G) <= NG) fill_rows(std::integral_constant<int, (G) <= NG ? (G) : 1>()); break;
+            switch (gend) {
+                SA_ROWS(1) SA_ROWS(2) SA_ROWS(3) SA_ROWS(4) SA_ROWS(5) SA_ROWS(6) SA_ROWS(7) SA_ROWS(8)
+                SA_ROWS(9) SA_ROWS(10) SA_ROWS(11) SA_ROWS(12) SA_ROWS(13) SA_ROWS(14) SA_ROWS(15) SA_ROWS(16)
+                default: break;
             }
+#undef SA_ROWS
             // the bank holds 16*D + a tag field per half
             const int d1 = (int)((dfin1 & 0xffffu) >> SA_NB_SHIFT);
             const int d2 = (int)(dfin2 >> (16 + SA_NB_SHIFT));
@@ -215,13 +238,19 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
                 const int mlen = __builtin_amdgcn_readfirstlane(wave_max(lq));
                 const int base = half ? half_off : 0;
                 int matches = 0, gaps = 0;
-#define SA_TRACEBACK(WW)                                                                                   \
-    traceback_pk<WW, PROF_BYTES + 4, SD>(lane, mlen, lq, lenp, spill, base, bw,                    \
-                                            stage + lane * SD, matches, gaps)
-                if (wpr == 4) SA_TRACEBACK(4);
-                else if (wpr == 3) SA_TRACEBACK(3);
-                else if (wpr == 2) SA_TRACEBACK(2);
-                else SA_TRACEBACK(1);
+#define SA_TRACEBACK(WD, ODD)                                                                              \
+    traceback_pk<WD, ODD, PROF_BYTES + 4, SD>(lane, mlen, lq, lenp, spill, base, bw,                       \
+                                              stage + lane * SD, matches, gaps)
+                switch (n16) {
+                    case 1: SA_TRACEBACK(0, 1); break;
+                    case 2: SA_TRACEBACK(1, 0); break;
+                    case 3: SA_TRACEBACK(1, 1); break;
+                    case 4: SA_TRACEBACK(2, 0); break;
+                    case 5: SA_TRACEBACK(2, 1); break;
+                    case 6: SA_TRACEBACK(3, 0); break;
+                    case 7: SA_TRACEBACK(3, 1); break;
+                    default: if constexpr (NG > 13) SA_TRACEBACK(4, 0); break;
+                }
 #undef SA_TRACEBACK
                 SA_PHASE(4);
                 const int score = (half ? d2 : d1) + (lenp + lenq) * P.gap;

@@ -12,6 +12,7 @@
 typedef uint32_t sa_u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t sa_u32x3 __attribute__((ext_vector_type(3)));
 typedef uint32_t sa_u32x4 __attribute__((ext_vector_type(4)));
+#include <type_traits>
 #define SA_BUFFER_FLAGS 0x00020000
 
 // ---------------------------------------------------------------- traceback
@@ -188,28 +189,45 @@ template <> struct SaDirWords<2> { typedef sa_u32x2 type; };
 template <> struct SaDirWords<3> { typedef sa_u32x3 type; };
 template <> struct SaDirWords<4> { typedef sa_u32x4 type; };
 
-template <int W, int PCOL_LDS_OFFSET, int STAGE_DWORDS>
+// dword M of a direction row in its register form (see traceback_pk): d = the row's full dwords, piece = its odd piece
+template <int WD, int ODD, int M, typename WORDS>
+__device__ __forceinline__ uint32_t sa_tb_word(const WORDS& d, const uint32_t piece) {
+    if constexpr (ODD == 1 && M == 0) return piece << 16;
+    else if constexpr (WD <= 1) return d;
+    else return d[M - ODD];
+}
+
+// A direction row of one pair is 8-column pieces of 16 bits, N16 = ceil(columns / 8) of them: WD = N16 / 2 dwords per
+// lane (64 lanes side by side: 256 * WD bytes) and, when N16 is odd (ODD = 1), one more 16-bit piece per lane behind
+// them (128 bytes) with the row's last eight columns.  In registers the row is W = WD + ODD dwords, the piece shifted
+// to the upper half of dword 0 (its lower half stands for columns past the row's end, which no walk looks at).
+template <int WD, int ODD, int PCOL_LDS_OFFSET, int STAGE_DWORDS>
 __device__ __forceinline__ void traceback_pk(const int lane, const int maxlen, const int lenq, const int lenp,
                                              const __amdgpu_buffer_rsrc_t spill, const int base_off,
                                              const uint32_t (&bw)[16],
                                              uint32_t* __restrict__ stage_rec, int& matches_out, int& gaps_out) {
-    typedef typename SaDirWords<W>::type words_t;
-    struct Chunk { words_t d[4]; };
+    constexpr int W = WD + ODD;
+    constexpr int ROW_BYTES = 64 * (4 * WD + 2 * ODD);
+    typedef typename SaDirWords<WD ? WD : 1>::type words_t;
+    struct Chunk { words_t d[4]; uint32_t piece[4]; };
     uint32_t s = 2u * (uint32_t)lenp + 1u, matches = 0, ups = 0;
-    const int lane_off = lane * W * 4;
+    const int lane_off = lane * WD * 4;
+    const int piece_off = 256 * WD + lane * 2;
 
     // row indices past the end of the longest sequence and chunk indices below 0 are clamped
     auto load_chunk = [&](int ch, Chunk& ck) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int r = min(4 * ch + k, maxlen - 1);   // wave-uniform
-            const int row_off = base_off + r * 256 * W;
-            if constexpr (W == 4) ck.d[k] = __builtin_amdgcn_raw_buffer_load_b128(spill, lane_off, row_off, 0);
-            else if constexpr (W == 3) ck.d[k] = __builtin_amdgcn_raw_buffer_load_b96(spill, lane_off, row_off, 0);
-            else if constexpr (W == 2) ck.d[k] = __builtin_amdgcn_raw_buffer_load_b64(spill, lane_off, row_off, 0);
-            else ck.d[k] = __builtin_amdgcn_raw_buffer_load_b32(spill, lane_off, row_off, 0);
+            const int row_off = base_off + r * ROW_BYTES;
+            if constexpr (WD == 4) ck.d[k] = __builtin_amdgcn_raw_buffer_load_b128(spill, lane_off, row_off, 0);
+            else if constexpr (WD == 3) ck.d[k] = __builtin_amdgcn_raw_buffer_load_b96(spill, lane_off, row_off, 0);
+            else if constexpr (WD == 2) ck.d[k] = __builtin_amdgcn_raw_buffer_load_b64(spill, lane_off, row_off, 0);
+            else if constexpr (WD == 1) ck.d[k] = __builtin_amdgcn_raw_buffer_load_b32(spill, lane_off, row_off, 0);
+            if constexpr (ODD == 1) ck.piece[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(spill, piece_off, row_off, 0);
         }
     };
+#define SA_TB_WORD(m) sa_tb_word<WD, ODD, ((m) < W ? (m) : 0)>(ck.d[k], ck.piece[k])
 
     auto process = [&](int ch, const Chunk& ck) {
         const uint32_t b4 = pick_word(bw, ch);
@@ -224,20 +242,20 @@ __device__ __forceinline__ void traceback_pk(const int lane, const int maxlen, c
                 // round and the window is meaningless, not above 0 elsewhere
                 const int lo = (int)sh + 1;
                 if constexpr (W == 1) {
-                    L = min(sa_ffbl(ck.d[k] >> (sh & 31)), s);
+                    L = min(sa_ffbl(SA_TB_WORD(0) >> (sh & 31)), s);
                 } else if constexpr (W == 2) {
-                    const uint64_t v = ((uint64_t)ck.d[k].y << 32) | ck.d[k].x;
+                    const uint64_t v = ((uint64_t)SA_TB_WORD(1) << 32) | SA_TB_WORD(0);
                     L = min(sa_ctz64_sat(v >> (sh & 63)), s);
                 } else {
                     // columns 0..31 in one 64-bit half, 32..63 in the other; a run that starts in the upper
                     // half and finds nothing there goes on from column 31
                     uint64_t v0, v1;
                     if constexpr (W == 4) {
-                        v0 = ((uint64_t)ck.d[k].w << 32) | ck.d[k].z;
-                        v1 = ((uint64_t)ck.d[k].y << 32) | ck.d[k].x;
+                        v0 = ((uint64_t)SA_TB_WORD(3) << 32) | SA_TB_WORD(2);
+                        v1 = ((uint64_t)SA_TB_WORD(1) << 32) | SA_TB_WORD(0);
                     } else {
-                        v0 = ((uint64_t)ck.d[k].z << 32) | ck.d[k].y;
-                        v1 = (uint64_t)ck.d[k].x << 32;
+                        v0 = ((uint64_t)SA_TB_WORD(2) << 32) | SA_TB_WORD(1);
+                        v1 = (uint64_t)SA_TB_WORD(0) << 32;
                     }
                     const bool upper = s > 65u;
                     const uint32_t lx = sa_ctz64_sat((upper ? v1 : v0) >> (sh & 63));
@@ -294,6 +312,7 @@ __device__ __forceinline__ void traceback_pk(const int lane, const int maxlen, c
     for (int z = ((maxlen - 1) >> 2) + 1; z < STAGE_DWORDS - 2; z++) stage_rec[2 + z] = 0;
     matches_out = (int)matches;
     gaps_out = (int)ups;
+#undef SA_TB_WORD
 }
 
 #endif
