@@ -185,8 +185,9 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
             // The row loop, once per row length: with the number of groups a constant the row is straight-line code
             // (no compare and branch per group, no test before a table request) and the shape of the direction stores
             // is fixed.  Items come sorted by length, so the waves of a CU run the same copy most of the time.
-            auto fill_rows = [&](auto GC) {
-                constexpr int GEND = decltype(GC)::value;
+            auto fill_rows = [&](auto EC) {
+                constexpr int END2 = decltype(EC)::value;                      // column pairs per row
+                const std::integral_constant<int, (END2 + 1) / 2> GC;          // groups of four columns
                 uint32_t o0 = qres[0] * PS;      // profile row (as a dword offset) of the row to come
                 for (int r = 0; r < maxlen; r++) {
                     const uint32_t b1 = qres[min(r + 1, SA_LP - 1)];
@@ -194,7 +195,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
                     // residues; those rows are never read): with the row under a per-lane condition the compiler
                     // keeps a second copy of the register row for the lanes that skip it.  A lane takes its
                     // scores when its last row is done.
-                    fill_row_pair<NG, PS, GEND>(R, GEND, SA_NB_UP_B, 0u, prof + o0, e);
+                    fill_row_pair<NG, PS, END2>(R, (END2 + 1) / 2, SA_NB_UP_B, 0u, prof + o0, e);
                     store_dirs(r, GC);
                     if (r + 1 == lenq) {
                         dfin1 = pick_packed<NC>(R, lenp1 - 1);
@@ -203,10 +204,12 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
                     o0 = b1 * PS;
                 }
             };
-#define SA_ROWS(G) case G: if constexpr ((G) <= NG) fill_rows(std::integral_constant<int, (G) <= NG ? (G) : 1>()); break;
-            switch (gend) {
+#define SA_ROWS(E) case E: if constexpr ((E) <= 2 * NG) fill_rows(std::integral_constant<int, (E) <= 2 * NG ? (E) : 1>()); break;
+            switch ((max(lenp1, lenp2) + 1) >> 1) {
                 SA_ROWS(1) SA_ROWS(2) SA_ROWS(3) SA_ROWS(4) SA_ROWS(5) SA_ROWS(6) SA_ROWS(7) SA_ROWS(8)
                 SA_ROWS(9) SA_ROWS(10) SA_ROWS(11) SA_ROWS(12) SA_ROWS(13) SA_ROWS(14) SA_ROWS(15) SA_ROWS(16)
+                SA_ROWS(17) SA_ROWS(18) SA_ROWS(19) SA_ROWS(20) SA_ROWS(21) SA_ROWS(22) SA_ROWS(23) SA_ROWS(24)
+                SA_ROWS(25) SA_ROWS(26) SA_ROWS(27) SA_ROWS(28) SA_ROWS(29) SA_ROWS(30) SA_ROWS(31) SA_ROWS(32)
                 default: break;
             }
 #undef SA_ROWS

@@ -69,8 +69,9 @@
         zl = MB;                                                                                \
     }
 
-// Four columns.  Rows end early: gend = ceil(longer first sequence / 4), a run-time value when the template
-// argument GEND is 0 and GEND itself otherwise (no test per group then: the row is straight-line code).
+// Four columns.  Rows end early: after gend = ceil(longer first sequence / 4) groups, a run-time value, when the
+// template argument END2 is 0; otherwise after END2 = ceil(longer first sequence / 2) column pairs, a constant: no
+// test per group then (the row is straight-line code), and a last group of one column pair is half a group.
 // Profile rows are stored one column to the left: dword k of a row holds the table entry of column k + 1, the
 // entry of column 0 stands in the row's last dword (PS - 1).  The four entries group G reads are then those of
 // columns 4G+1 .. 4G+4, all it needs: the diagonal operands of its own columns 4G+1, 4G+2, 4G+3 and of the next
@@ -91,24 +92,28 @@ typedef int sa_i32x2 __attribute__((ext_vector_type(2)));
 #define SA_PROF_AWAIT(LO, HI) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(LO), "+v"(HI))
 #define SA_GROUP_PK(G)                                                                          \
     {                                                                                           \
+        /* END2 != 0: the row is END2 column pairs long, a constant; else gend groups, a run-time value */ \
+        constexpr bool last_ = NG == (G) + 1 || (END2 != 0 && 2 * (G) + 2 >= END2);             \
+        constexpr bool half_ = END2 != 0 && 2 * (G) + 1 == END2;                                \
         sa_i32x4 sc_;                                                                           \
         if (((G) & 1) == 0) {                                                                   \
             SA_PROF_AWAIT(pa_lo, pa_hi);                                                        \
-            if ((G) + 1 < NG && (GEND ? GEND != (G) + 1 : gend != (G) + 1)) SA_PROF_REQUEST(pb_lo, pb_hi, (G) + 1);        \
+            if (!last_ && (END2 != 0 || gend != (G) + 1)) SA_PROF_REQUEST(pb_lo, pb_hi, (G) + 1); \
             sc_.x = pa_lo.x; sc_.y = pa_lo.y; sc_.z = pa_hi.x; sc_.w = pa_hi.y;                 \
         } else {                                                                                \
             SA_PROF_AWAIT(pb_lo, pb_hi);                                                        \
-            if ((G) + 1 < NG && (GEND ? GEND != (G) + 1 : gend != (G) + 1)) SA_PROF_REQUEST(pa_lo, pa_hi, (G) + 1);        \
+            if (!last_ && (END2 != 0 || gend != (G) + 1)) SA_PROF_REQUEST(pa_lo, pa_hi, (G) + 1); \
             sc_.x = pb_lo.x; sc_.y = pb_lo.y; sc_.z = pb_hi.x; sc_.w = pb_hi.y;                 \
         }                                                                                       \
         uint32_t mb0_ = B[4 * (G)] + (uint32_t)sc_.x;                                           \
         uint32_t ma1_ = B[4 * (G) + 1] + (uint32_t)sc_.y;                                       \
         SA_CELL_NB(B, 4 * (G), ma_, mb0_, e[(G) >> 1])                                          \
+        if (half_) return;                                                                      \
         uint32_t mb1_ = B[4 * (G) + 2] + (uint32_t)sc_.z;                                       \
         uint32_t man_ = 0;                                                                      \
-        if ((G) + 1 < NG) asm volatile("v_add_u32 %0, %1, %2" : "=v"(man_) : "v"(B[4 * (G) + 3]), "v"(sc_.w)); \
+        if (!last_) asm volatile("v_add_u32 %0, %1, %2" : "=v"(man_) : "v"(B[4 * (G) + 3]), "v"(sc_.w)); \
         SA_CELL_NB(B, 4 * (G) + 2, ma1_, mb1_, e[(G) >> 1])                                     \
-        if (NG == (G) + 1 || (GEND ? GEND == (G) + 1 : gend == (G) + 1)) return;                \
+        if (last_ || (END2 == 0 && gend == (G) + 1)) return;                                    \
         ma_ = man_;                                                                             \
     }
 
@@ -118,7 +123,7 @@ typedef int sa_i32x2 __attribute__((ext_vector_type(2)));
 // lane's profile row, PS dwords long, laid out as described above.
 // e[w] receives the tags of columns 8w .. 8w+7 of both pairs: column 8w+i at bits 2(7-i) of each 16-bit
 // half, also when the row ends after four columns of the word.
-template <int NG, int PS, int GEND = 0>
+template <int NG, int PS, int END2 = 0>
 __device__ __forceinline__ void fill_row_pair(uint32_t (&B)[4 * NG], const int gend,
                                               const uint32_t diag0, const uint32_t left0,
                                               const int32_t* __restrict__ row_base, uint32_t (&e)[(NG + 1) / 2]) {
