@@ -288,8 +288,9 @@ int build_items(sa_ctx* c, int schedule, uint64_t r0, uint64_t r1, std::vector<S
     int rc = ensure_triangular(c);
     if (rc) return rc;
     // long sequences: one 64-pair tile is already milliseconds of work, and few items per workgroup leave a long tail
-    // peptides: many tiles per item spread the cost of an item's query profile (16 measured 1.5 % faster than 8 on
-    // 10^7 tiles), few keep the tail short when the range is small: at least 32 items per workgroup, at most 16 tiles
+    // peptides: many tiles per item spread the cost of an item's query profile (on 10^7 tiles: 4 tiles 111 ms, 8 108,
+    // 16 105.1, 32 104.7, 64 105.2, 128 107.4; tools/knob_sweep.py), few keep the tail short when the range is small:
+    // at least 32 items per workgroup, at most 32 tiles
     uint32_t per = 1;
     if (!is_long(c)) {
         per = c->tiles_per_item;
@@ -297,7 +298,7 @@ int build_items(sa_ctx* c, int schedule, uint64_t r0, uint64_t r1, std::vector<S
             const uint64_t tiles = sa_pair_count(c, schedule, r0, r1) / (uses_pairs(c) && paired ? 128 : 64);
             const uint64_t want = tiles / (std::max<uint64_t>(1, grid_for(c)) * 32);
             per = 1;
-            while (per < 16 && per * 2 <= want) per *= 2;
+            while (per < 32 && per * 2 <= want) per *= 2;
         }
     }
     const uint32_t nb = c->nb;

@@ -41,6 +41,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
         if (lane == 0) atomicOr(P.counter + SA_STATUS_WORD, SA_STATUS_LDS_BASE);
         return;
     }
+    if (lane < 4) pcol[lane] = 0xff;     // the bytes in front of column 0's residue code (see traceback_pk)
     // rows 0..63 of the spill area hold the direction rows of the low halves, rows 64..127 those of the high halves
     const __amdgpu_buffer_rsrc_t spill = __builtin_amdgcn_make_buffer_rsrc(
         P.spill + (size_t)blockIdx.x * P.spill_rows * 256, 0, P.spill_rows * 1024, SA_BUFFER_FLAGS);
@@ -236,7 +237,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
                 if (!__any(act)) continue;
                 const int lenp = half ? lenp2 : lenp1;
                 const int lq = act ? lenq : 0;
-                reinterpret_cast<uint16_t*>(pcol + 4)[lane] = pcol[192 + 64 * half + lane];
+                reinterpret_cast<uint16_t*>(pcol + 4)[lane] = (uint16_t)(0xff00u | pcol[192 + 64 * half + lane]);
                 __syncthreads();
                 const int mlen = __builtin_amdgcn_readfirstlane(wave_max(lq));
                 const int base = half ? half_off : 0;

@@ -158,8 +158,9 @@ __device__ __forceinline__ void traceback(const int lane, const int maxlen, cons
 //    0 and the window holds the unshifted row: there L is forced to 1 by a lower bound, 2 - s, that is negative elsewhere.)  L is
 //    also the output byte (2 * run + up).
 //  * Matches: the first sequence's residue codes lie in LDS two bytes apart (column c at pcol[2c]), so the byte
-//    address of the column a DIAG move consumes is s - L - 3, no shift; on an UP move bit 8 is set in the value
-//    read and the comparison with the row's residue fails.  (Handing the value read to the next row's block, so
+//    address of the column a DIAG move consumes is s - L - 3, no shift; an UP move reads an odd address, one of the
+//    bytes in between (or of the three bytes in front of column 0), which hold 0xff, no residue code: the
+//    comparison with the row's residue fails without a look at the kind of move.  (Handing the value read to the next row's block, so
 //    that nothing waits for the LDS, made no difference on the same machine and was dropped.)
 //  * The dwords of a direction row are stored last first (dword m = columns 16(W-1-m) .. 16(W-1-m)+15), so that
 //    the register pair a 64-bit load fills is the 64-bit window value, lower columns in the upper half.
@@ -177,12 +178,25 @@ __device__ __forceinline__ uint32_t sa_ctz64_sat(uint64_t x) { // trailing zeros
     return min(fl, fh);
 }
 
+__device__ __forceinline__ uint32_t sa_ctz64_min(uint64_t x, uint32_t cap) { // min(trailing zeros of x, cap)
+    uint32_t fl, fh;
+    asm("v_ffbl_b32 %0, %2\n\tv_ffbl_b32 %1, %3\n\tv_add_u32 %1, %1, 32 clamp\n\tv_min3_u32 %0, %0, %1, %4"
+        : "=&v"(fl), "=&v"(fh) : "v"((uint32_t)x), "v"((uint32_t)(x >> 32)), "v"(cap));
+    return fl;
+}
+
 // PCOL_LDS_OFFSET: byte address of column 0's residue code inside the workgroup's LDS (at least 3);
 // STAGE_DWORDS: dwords of the lane's staging record (2 of header, the rest one byte per row).
 //  * The direction words of a chunk (four rows) are requested two chunks ahead of their use, three register sets
-//    in turn.  (The compiler cannot follow the rotation through the loop and waits for everything in flight in
-//    front of a chunk's first use; hand-written requests with counted waits, "at most 8 outstanding", kept the two
-//    younger chunks in flight but changed nothing on the same machine with four waves per SIMD, and were dropped.)
+//    in turn.  (Hand-written requests with counted waits, "at most 8 outstanding", changed nothing on the same
+//    machine with four waves per SIMD, and were dropped.)
+// register sets of the traceback's row requests, by row width in dwords (measured: 3 to 6 sets make no difference)
+#ifndef SA_TB_SETS_W1
+#define SA_TB_SETS_W1 3
+#define SA_TB_SETS_W2 3
+#define SA_TB_SETS_W3 3
+#define SA_TB_SETS_W4 3
+#endif
 template <int W> struct SaDirWords;
 template <> struct SaDirWords<1> { typedef uint32_t type; };
 template <> struct SaDirWords<2> { typedef sa_u32x2 type; };
@@ -245,7 +259,7 @@ __device__ __forceinline__ void traceback_pk(const int lane, const int maxlen, c
                     L = min(sa_ffbl(SA_TB_WORD(0) >> (sh & 31)), s);
                 } else if constexpr (W == 2) {
                     const uint64_t v = ((uint64_t)SA_TB_WORD(1) << 32) | SA_TB_WORD(0);
-                    L = min(sa_ctz64_sat(v >> (sh & 63)), s);
+                    L = sa_ctz64_min(v >> (sh & 63), s);
                 } else {
                     // columns 0..31 in one 64-bit half, 32..63 in the other; a run that starts in the upper
                     // half and finds nothing there goes on from column 31
@@ -278,7 +292,6 @@ __device__ __forceinline__ void traceback_pk(const int lane, const int maxlen, c
                  "v_mad_u32_u24 %[s], %[tn], 3, %[rest]\n\t"                                                 \
                  "v_add_u32 %[s], -2, %[s]\n\t"                                                              \
                  "s_waitcnt lgkmcnt(0)\n\t"                                                                  \
-                 "v_lshl_or_b32 %[an], %[tn], 8, %[an]\n\t"                                                  \
                  "v_cmp_eq_u32_sdwa vcc, %[an], %[bo] src0_sel:DWORD src1_sel:BYTE_" #K "\n\t"               \
                  "v_addc_co_u32 %[m], vcc, 0, %[m], vcc"                                                     \
                  : [an] "=&v"(an_), [tn] "=&v"(tn_), [packed] "+&v"(packed), [s] "=&v"(s), [m] "+&v"(matches) \
@@ -292,20 +305,24 @@ __device__ __forceinline__ void traceback_pk(const int lane, const int maxlen, c
         stage_rec[2 + ch] = packed;
     };
 
-    // Three sets of registers take turns: step i requests chunk top - i into set i mod 3 and works on chunk
-    // top - i + 2, requested two steps earlier.
-    Chunk c0, c1, c2;
+    // NS sets of registers take turns: the chunk worked on was requested NS - 1 chunks earlier.  (Without the row
+    // requests -- every chunk reading the same four rows -- a launch of 50 000 peptides is 10 % shorter, without the
+    // work on the rows 5 %; yet four or six sets instead of three changed nothing: what the requests cost is their
+    // share of the memory system's throughput, not the time one of them takes.)
+    constexpr int NS = W <= 1 ? SA_TB_SETS_W1 : W == 2 ? SA_TB_SETS_W2 : W == 3 ? SA_TB_SETS_W3 : SA_TB_SETS_W4;
+    Chunk c[NS];
     const int top = (maxlen - 1) >> 2;
-    for (int t = top; t >= -2; t -= 3) {
-        load_chunk(max(t, 0), c0);
-        if (t + 2 <= top) process(t + 2, c1);
-        if (t >= -1) {
-            load_chunk(max(t - 1, 0), c1);
-            if (t + 1 <= top) process(t + 1, c2);
-        }
-        if (t >= 0) {
-            load_chunk(max(t - 2, 0), c2);
-            process(t, c0);
+#pragma unroll
+    for (int j = 0; j < NS - 1; j++)
+        if (top - j >= 0) load_chunk(top - j, c[j]);
+    for (int t = top; t >= 0; t -= NS) {
+#pragma unroll
+        for (int j = 0; j < NS; j++) {
+            const int ch = t - j;                 // the chunk in set j
+            if (ch >= 0) {
+                if (ch - (NS - 1) >= 0) load_chunk(ch - (NS - 1), c[(j + NS - 1) % NS]);
+                process(ch, c[j]);
+            }
         }
     }
     // body bytes past the last chunk are zero, so that equal inputs give equal records
