@@ -42,7 +42,8 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
         return;
     }
     if (lane < 4) pcol[lane] = 0xff;     // the bytes in front of column 0's residue code (see traceback_pk)
-    // rows 0..63 of the spill area hold the direction rows of the low halves, rows 64..127 those of the high halves
+    // the workgroup's part of the spill area (128 KiB): the direction rows of the low halves, then those of the high
+    // halves, each row as long as the task's first sequences need (see store_dirs)
     const __amdgpu_buffer_rsrc_t spill = __builtin_amdgcn_make_buffer_rsrc(
         P.spill + (size_t)blockIdx.x * P.spill_rows * 256, 0, P.spill_rows * 1024, SA_BUFFER_FLAGS);
     const uint32_t cpr = P.stride >> 4;   // 16-byte chunks per record
