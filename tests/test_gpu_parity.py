@@ -868,3 +868,43 @@ def test_wave_per_pair_kernel_on_awkward_shapes():
         assert al.last_kernel().startswith("sa_long_kernel")
         _check_pairs(al, tri, _tri_pairs(n, 0, n - 1), gap=gap, matrix=mat)
         _check_pairs(al, adj, [(k, k + 1) for k in range(n - 1)], gap=gap, matrix=mat)
+
+
+@pytest.mark.gpu
+def test_every_first_sequence_length_of_the_paired_kernel():
+    """The paired peptide kernel has one copy of its row loop per row length (in column pairs) and one shape of
+    direction row per eight columns: a set with 70 sequences of every length 1..64 runs each copy with full waves of
+    partners of all lengths.  Paired and 32-bit kernels must agree on every record; rows of every length are
+    checked against the oracle."""
+    rng = random.Random(77)
+    seqs = []
+    for length in range(1, 65):
+        for _ in range(70):
+            seqs.append("".join(rng.choice(ALPHABET) for _ in range(length)))
+    rng.shuffle(seqs)
+    n = len(seqs)
+    al = sa.Aligner(max_seq_len=64)
+    al.upload(seqs)
+    paired = al.align(sa.TRIANGULAR)
+    assert al.last_kernel().startswith("sa_peptide_pair_kernel<16")
+    al.set_pairing(False)
+    unpaired = al.align(sa.TRIANGULAR)
+    assert np.array_equal(paired, unpaired)
+    seen = set()
+    for i in range(n - 64):
+        if len(seqs[i]) in seen:
+            continue
+        seen.add(len(seqs[i]))
+        first = al.pair_index(sa.TRIANGULAR, i)
+        pairs = [(i, j) for j in range(i + 1, min(n, i + 1 + 300))]
+        _check_pairs(al, paired[first : first + len(pairs)], pairs)
+    assert len(seen) == 64
+
+    # the 52-column variant: lengths 1..52 only
+    short = [s for s in seqs if len(s) <= 52]
+    al2 = sa.Aligner(max_seq_len=64)
+    al2.upload(short)
+    paired2 = al2.align(sa.TRIANGULAR)
+    assert al2.last_kernel().startswith("sa_peptide_pair_kernel<13")
+    al2.set_pairing(False)
+    assert np.array_equal(paired2, al2.align(sa.TRIANGULAR))
