@@ -240,6 +240,13 @@ bool write_all(int fd, const char* p, size_t n) {
     return true;
 }
 
+// Blocks for a chunk's part of the output file, taken in one call before its slices are written side by side: on a
+// disk file system the writers otherwise allocate under the inode lock one after the other (500 MB in 16 slices:
+// 0.080 s without, 0.045 s with, tools/write_bench.cpp); where the file system cannot do it the call fails and nothing is lost.
+void reserve_blocks(int fd, uint64_t at, uint64_t nbytes) {
+    if (nbytes) (void)fallocate(fd, 0, (off_t)at, (off_t)nbytes);
+}
+
 bool pwrite_all(int fd, const char* p, size_t n, uint64_t off) {
     while (n) {
         ssize_t w = pwrite(fd, p, n, (off_t)off);
@@ -670,6 +677,7 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
                     writer = std::thread([&, k, text, nbytes]() {
                         uint64_t at = 0;
                         if (!offset_of(k, at)) return;
+                        reserve_blocks(out_fd, at, nbytes);
                         sa_parallel_for(nbytes, 1 << 22, [&](uint64_t lo, uint64_t hi, unsigned) {
                             if (!pwrite_all(out_fd, text + lo, hi - lo, at + lo)) write_failed.store(true);
                         });
@@ -728,6 +736,7 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
                     writer = std::thread([&, k, total_bytes, cur_set]() {
                         uint64_t chunk_off = 0;
                         if (!offset_of(k, chunk_off)) return;
+                        reserve_blocks(out_fd, chunk_off, total_bytes);
                         std::vector<std::vector<char>>& wb = bufset[cur_set];
                         std::vector<size_t>& wu = usedset[cur_set];
                         std::vector<uint64_t> at((size_t)fthreads + 1, chunk_off);
