@@ -318,8 +318,8 @@ def e2e_mega(sa, mega_path, out_dir, device):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="peptides50k", choices=sorted(WORKLOADS))
     ap.add_argument("--no-extra", action="store_true", help="skip the side measurements (32-bit kernel, PCIe, CSV end to end, proteins)")
     ap.add_argument("--cpu-sample", type=int, default=8000, help="sequences in the CPU restatement's sample (0 = no CPU baseline)")
