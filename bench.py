@@ -353,7 +353,12 @@ def main():
         local_rank = int(os.environ["SA_BENCH_DEVICE"])
     if world > 1:
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(os.environ.get("SA_BENCH_BACKEND", "nccl"))
+        backend = os.environ.get("SA_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            # the communicator is bound to this rank's GPU at once: barriers need not guess a device
+            dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     def barrier_sync():
         if world > 1:
