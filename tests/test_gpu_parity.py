@@ -908,3 +908,26 @@ def test_every_first_sequence_length_of_the_paired_kernel():
     assert al2.last_kernel().startswith("sa_peptide_pair_kernel<13")
     al2.set_pairing(False)
     assert np.array_equal(paired2, al2.align(sa.TRIANGULAR))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cooperative", [0, 1])
+def test_csv_driver_with_several_contexts_on_long_sequences(tmp_path, cooperative):
+    """Two contexts on one card over a file of long sequences, all-vs-all in small submissions: with the library's own
+    choice of kernel (few pairs per submission: one wave per pair) and with that kernel forced; both formatting
+    modes; same bytes as the checker."""
+    seqs, labels = synth.generate(60, 80, 700, 93)
+    src = tmp_path / "in.csv"
+    synth.write_csv(str(src), seqs, labels)
+    want, got = tmp_path / "oracle.csv", tmp_path / "gpu.csv"
+    oracle_lib.run_file(str(src), str(want), sa.TRIANGULAR, threads=8)
+    for device_format in (1, 0):
+        st = sa.default_settings()
+        st.num_devices = 2
+        st.devices[0] = st.devices[1] = 0
+        st.max_seq_len = 1024
+        st.cooperative = cooperative
+        st.device_format = device_format
+        rep = sa.run_csv(str(src), str(got), sa.TRIANGULAR, settings=st, pairs_per_submit=300)
+        assert rep.chunks_done >= 4
+        assert got.read_bytes() == want.read_bytes()
