@@ -166,7 +166,13 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_pair_kernel(const 
                 // read): with the row under a per-lane condition the compiler keeps a second copy of the register row
                 // for the lanes that skip it.  A lane takes its scores when its last row is done.
 #define SA_LP_ROW(RR, DA, DB, LA, LB, B)                                                                                  \
-    fill_row_pair<SA_LP / 4, SA_LONG_PAIR_PROF_STRIDE>(R, gend, rel(DA, DB) | SA_NB_UP_B, rel(LA, LB), prof + (B) * SA_LONG_PAIR_PROF_STRIDE, e);              \
+    {                                                                                                                      \
+        /* the row's end tests compare this copy of gend where they stand: hoisted out of the loop each of them holds a */  \
+        /* pair of scalar registers (more than there are) and comes back as two vector instructions per group            */ \
+        int gr_ = gend;                                                                                                    \
+        asm volatile("" : "+s"(gr_));                                                                                      \
+        fill_row_pair<SA_LP / 4, SA_LONG_PAIR_PROF_STRIDE>(R, gr_, rel(DA, DB) | SA_NB_UP_B, rel(LA, LB), prof + (B) * SA_LONG_PAIR_PROF_STRIDE, e);           \
+    }                                                                                                                      \
     store_dirs(RR);                                                                                                        \
     if ((RR) + 1 == lenq) {                                                                                                \
         capA = (int)((pick_packed<SA_LP>(R, colA) & 0xffffu) >> SA_NB_SHIFT) + base1;                                      \
