@@ -127,11 +127,16 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
             {
                 const uint4* src = reinterpret_cast<const uint4*>(P.codes_s + (size_t)sidx * SA_LP);
                 uint2* dst = reinterpret_cast<uint2*>(qres);
+                // only the 16-byte pieces that hold residues of the wave's longest second sequence (plus the one
+                // the row loop's look-ahead may touch): slots are fetched from beyond the L2 in 32-byte sectors
+                const int nq = min(4, (maxlen >> 4) + 1);
 #pragma unroll
                 for (int q4 = 0; q4 < 4; q4++) {
-                    const uint4 v = src[q4];
-                    dst[2 * q4] = make_uint2(v.x, v.y);
-                    dst[2 * q4 + 1] = make_uint2(v.z, v.w);
+                    if (q4 < nq) {
+                        const uint4 v = src[q4];
+                        dst[2 * q4] = make_uint2(v.x, v.y);
+                        dst[2 * q4 + 1] = make_uint2(v.z, v.w);
+                    }
                 }
             }
             // Direction rows, one pair at a time: 16-bit pieces of eight columns, n16 per row and lane; the rows of the
@@ -143,7 +148,6 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
             auto store_dirs = [&](int r, auto GC) {
                 constexpr int GEND = decltype(GC)::value;
                 constexpr int N16 = (GEND + 1) / 2, WD = N16 / 2, ODD = N16 & 1;
-                const int dir_lane = lane * (WD * 4);
                 const int row_off = r * (128 * N16);
                 const int hoff = SA_LP * (128 * N16) + row_off;
                 uint32_t lo[4], hi[4];
@@ -157,22 +161,25 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
                         lo[k] = hi[k] = 0;
                     }
                 }
-                // last dword first (see traceback_pk)
-                if constexpr (WD == 4) {
-                    const sa_u32x4 a = {lo[3], lo[2], lo[1], lo[0]}, b = {hi[3], hi[2], hi[1], hi[0]};
-                    __builtin_amdgcn_raw_buffer_store_b128(a, spill, dir_lane, row_off, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(b, spill, dir_lane, hoff, 0);
-                } else if constexpr (WD == 3) {
-                    const sa_u32x3 a = {lo[2], lo[1], lo[0]}, b = {hi[2], hi[1], hi[0]};
-                    __builtin_amdgcn_raw_buffer_store_b96(a, spill, dir_lane, row_off, 0);
-                    __builtin_amdgcn_raw_buffer_store_b96(b, spill, dir_lane, hoff, 0);
-                } else if constexpr (WD == 2) {
+                // Highest columns first; the dwords of the higher columns (WH of them) of all lanes stand in front
+                // of those of the lower columns (see traceback_pk, which stops requesting the former).
+                constexpr int WH = WD / 2, WL = WD - WH;
+                const int high_lane = lane * (WH * 4), low_lane = 256 * WH + lane * (WL * 4);
+                if constexpr (WH == 2) {
+                    const sa_u32x2 a = {lo[WD - 1], lo[WD - 2]}, b = {hi[WD - 1], hi[WD - 2]};
+                    __builtin_amdgcn_raw_buffer_store_b64(a, spill, high_lane, row_off, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(b, spill, high_lane, hoff, 0);
+                } else if constexpr (WH == 1) {
+                    __builtin_amdgcn_raw_buffer_store_b32(lo[WD - 1], spill, high_lane, row_off, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(hi[WD - 1], spill, high_lane, hoff, 0);
+                }
+                if constexpr (WL == 2) {
                     const sa_u32x2 a = {lo[1], lo[0]}, b = {hi[1], hi[0]};
-                    __builtin_amdgcn_raw_buffer_store_b64(a, spill, dir_lane, row_off, 0);
-                    __builtin_amdgcn_raw_buffer_store_b64(b, spill, dir_lane, hoff, 0);
-                } else if constexpr (WD == 1) {
-                    __builtin_amdgcn_raw_buffer_store_b32(lo[0], spill, dir_lane, row_off, 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(hi[0], spill, dir_lane, hoff, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(a, spill, low_lane, row_off, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(b, spill, low_lane, hoff, 0);
+                } else if constexpr (WL == 1) {
+                    __builtin_amdgcn_raw_buffer_store_b32(lo[0], spill, low_lane, row_off, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(hi[0], spill, low_lane, hoff, 0);
                 }
                 if constexpr (ODD == 1) {
                     // the row's last eight columns: the word's two halves are the two pairs' pieces as they stand

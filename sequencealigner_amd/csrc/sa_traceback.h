@@ -187,15 +187,18 @@ __device__ __forceinline__ uint32_t sa_ctz64_min(uint64_t x, uint32_t cap) { // 
 
 // PCOL_LDS_OFFSET: byte address of column 0's residue code inside the workgroup's LDS (at least 3);
 // STAGE_DWORDS: dwords of the lane's staging record (2 of header, the rest one byte per row).
-//  * The direction words of a chunk (four rows) are requested two chunks ahead of their use, three register sets
-//    in turn.  (Hand-written requests with counted waits, "at most 8 outstanding", changed nothing on the same
-//    machine with four waves per SIMD, and were dropped.)
-// register sets of the traceback's row requests, by row width in dwords (measured: 3 to 6 sets make no difference)
+//  * The direction words of a chunk (four rows) are requested a chunk ahead of their use, two register sets in turn.
+//    (Hand-written requests with counted waits, "at most 8 outstanding", changed nothing on the same machine with four
+//    waves per SIMD, and were dropped.)
+// Register sets of the traceback's row requests, by row width in dwords.  Three to six sets made no difference in time;
+// with two, a chunk is requested one chunk (four rows) before its use instead of two, so the decision which areas of
+// a row still have to be requested is made on a later state of the walk: 296 -> 286 GB read per launch of 50 000
+// peptides, and 0.6 % less time.
 #ifndef SA_TB_SETS_W1
-#define SA_TB_SETS_W1 3
-#define SA_TB_SETS_W2 3
-#define SA_TB_SETS_W3 3
-#define SA_TB_SETS_W4 3
+#define SA_TB_SETS_W1 2
+#define SA_TB_SETS_W2 2
+#define SA_TB_SETS_W3 2
+#define SA_TB_SETS_W4 2
 #endif
 template <int W> struct SaDirWords;
 template <> struct SaDirWords<1> { typedef uint32_t type; };
@@ -203,45 +206,62 @@ template <> struct SaDirWords<2> { typedef sa_u32x2 type; };
 template <> struct SaDirWords<3> { typedef sa_u32x3 type; };
 template <> struct SaDirWords<4> { typedef sa_u32x4 type; };
 
-// dword M of a direction row in its register form (see traceback_pk): d = the row's full dwords, piece = its odd piece
-template <int WD, int ODD, int M, typename WORDS>
-__device__ __forceinline__ uint32_t sa_tb_word(const WORDS& d, const uint32_t piece) {
-    if constexpr (ODD == 1 && M == 0) return piece << 16;
-    else if constexpr (WD <= 1) return d;
-    else return d[M - ODD];
+// Scalar or vector of W dwords, element i
+template <int W, typename WORDS>
+__device__ __forceinline__ uint32_t sa_tb_elem(const WORDS& d, const int i) {
+    if constexpr (W <= 1) return d;
+    else return d[i];
 }
 
-// A direction row of one pair is 8-column pieces of 16 bits, N16 = ceil(columns / 8) of them: WD = N16 / 2 dwords per
-// lane (64 lanes side by side: 256 * WD bytes) and, when N16 is odd (ODD = 1), one more 16-bit piece per lane behind
-// them (128 bytes) with the row's last eight columns.  In registers the row is W = WD + ODD dwords, the piece shifted
-// to the upper half of dword 0 (its lower half stands for columns past the row's end, which no walk looks at).
+// A direction row of one pair is 8-column pieces of 16 bits, N16 = ceil(columns / 8) of them, that is WD = N16 / 2
+// dwords and, for odd N16 (ODD = 1), one more piece with the row's last eight columns.  In memory a row of the wave is
+// three areas: the WH = WD / 2 dwords of the higher columns of every lane (64 lanes side by side), the WL = WD - WH
+// dwords of the lower columns, the pieces (128 bytes).  The walk moves towards column 0 and never looks at a column
+// above the one it stands in: once every lane of the wave has left the higher columns their area is not requested any
+// more (a third of the row requests' bytes on the bench set), and likewise the pieces.
+// In registers the row is W = WD + ODD dwords, highest columns in dword 0: the piece shifted to the upper half of
+// dword 0 (its lower half stands for columns past the row's end), then the higher area's dwords, then the lower's.
 template <int WD, int ODD, int PCOL_LDS_OFFSET, int STAGE_DWORDS>
 __device__ __forceinline__ void traceback_pk(const int lane, const int maxlen, const int lenq, const int lenp,
                                              const __amdgpu_buffer_rsrc_t spill, const int base_off,
                                              const uint32_t (&bw)[16],
                                              uint32_t* __restrict__ stage_rec, int& matches_out, int& gaps_out) {
     constexpr int W = WD + ODD;
+    constexpr int WH = WD / 2, WL = WD - WH;
+    constexpr int NS = W <= 1 ? SA_TB_SETS_W1 : W == 2 ? SA_TB_SETS_W2 : W == 3 ? SA_TB_SETS_W3 : SA_TB_SETS_W4;   // register sets
     constexpr int ROW_BYTES = 64 * (4 * WD + 2 * ODD);
-    typedef typename SaDirWords<WD ? WD : 1>::type words_t;
-    struct Chunk { words_t d[4]; uint32_t piece[4]; };
-    uint32_t s = 2u * (uint32_t)lenp + 1u, matches = 0, ups = 0;
-    const int lane_off = lane * WD * 4;
+    typedef typename SaDirWords<WL ? WL : 1>::type low_t;
+    typedef typename SaDirWords<WH ? WH : 1>::type high_t;
+    struct Chunk { low_t lo[4]; high_t hi[4]; uint32_t piece[4]; };
+    // lanes without a pair keep state 0: they neither walk nor hold the wave in the higher columns
+    uint32_t s = lenq > 0 ? 2u * (uint32_t)lenp + 1u : 0u, matches = 0, ups = 0;
+    const int high_off = lane * WH * 4;
+    const int low_off = 256 * WH + lane * WL * 4;
     const int piece_off = 256 * WD + lane * 2;
 
-    // row indices past the end of the longest sequence and chunk indices below 0 are clamped
+    // Rows of chunk ch; the state s = 2 * (column + 1) + 1 only falls, so what no lane needs now it will not need later.
+    // The first request into each register set asks for everything, so that every register holds a row's bits.
     auto load_chunk = [&](int ch, Chunk& ck) {
+        const bool first = ch > ((maxlen - 1) >> 2) - NS;
+        const bool need_high = WH > 0 && (first || __any(s >= 32u * WL + 3u));
+        const bool need_piece = ODD == 1 && (first || __any(s >= 32u * WD + 3u));
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int r = min(4 * ch + k, maxlen - 1);   // wave-uniform
             const int row_off = base_off + r * ROW_BYTES;
-            if constexpr (WD == 4) ck.d[k] = __builtin_amdgcn_raw_buffer_load_b128(spill, lane_off, row_off, 0);
-            else if constexpr (WD == 3) ck.d[k] = __builtin_amdgcn_raw_buffer_load_b96(spill, lane_off, row_off, 0);
-            else if constexpr (WD == 2) ck.d[k] = __builtin_amdgcn_raw_buffer_load_b64(spill, lane_off, row_off, 0);
-            else if constexpr (WD == 1) ck.d[k] = __builtin_amdgcn_raw_buffer_load_b32(spill, lane_off, row_off, 0);
-            if constexpr (ODD == 1) ck.piece[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(spill, piece_off, row_off, 0);
+            if constexpr (WL == 2) ck.lo[k] = __builtin_amdgcn_raw_buffer_load_b64(spill, low_off, row_off, 0);
+            else if constexpr (WL == 1) ck.lo[k] = __builtin_amdgcn_raw_buffer_load_b32(spill, low_off, row_off, 0);
+            if (need_high) {
+                if constexpr (WH == 2) ck.hi[k] = __builtin_amdgcn_raw_buffer_load_b64(spill, high_off, row_off, 0);
+                else if constexpr (WH == 1) ck.hi[k] = __builtin_amdgcn_raw_buffer_load_b32(spill, high_off, row_off, 0);
+            }
+            if (need_piece) ck.piece[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(spill, piece_off, row_off, 0);
         }
     };
-#define SA_TB_WORD(m) sa_tb_word<WD, ODD, ((m) < W ? (m) : 0)>(ck.d[k], ck.piece[k])
+    // dword m of row k of a chunk in the register form described above
+#define SA_TB_WORD(m) ((ODD == 1 && (m) == 0) ? ck.piece[k] << 16                                                   \
+                       : ((m) - ODD < WH) ? sa_tb_elem<WH>(ck.hi[k], ((m) - ODD < WH && (m) >= ODD) ? (m) - ODD : 0) \
+                                          : sa_tb_elem<WL>(ck.lo[k], ((m) - ODD >= WH && (m) - ODD - WH < WL) ? (m) - ODD - WH : 0))
 
     auto process = [&](int ch, const Chunk& ck) {
         const uint32_t b4 = pick_word(bw, ch);
@@ -309,7 +329,6 @@ __device__ __forceinline__ void traceback_pk(const int lane, const int maxlen, c
     // requests -- every chunk reading the same four rows -- a launch of 50 000 peptides is 10 % shorter, without the
     // work on the rows 5 %; yet four or six sets instead of three changed nothing: what the requests cost is their
     // share of the memory system's throughput, not the time one of them takes.)
-    constexpr int NS = W <= 1 ? SA_TB_SETS_W1 : W == 2 ? SA_TB_SETS_W2 : W == 3 ? SA_TB_SETS_W3 : SA_TB_SETS_W4;
     Chunk c[NS];
     const int top = (maxlen - 1) >> 2;
 #pragma unroll
