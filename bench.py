@@ -307,8 +307,8 @@ def e2e_mega(sa, mega_path, out_dir, device):
             "device_wait": [round(best.device_wait[k], 4) for k in range(ndev)],
             "device_submit": [round(best.device_submit[k], 4) for k in range(ndev)],
             "device_write": [round(best.device_write[k], 4) for k in range(ndev)]}
-    # MODE_WRITE 0 (the reference's "without write"): what is left is the host pipeline itself, which must not get
-    # slower with the number of contexts it feeds
+    # MODE_WRITE 0 (the reference's "without write"): what is left is the host pipeline itself and, per further context,
+    # its set-up (clone of the sequences, pinned and device buffers)
     for ndev in (1, 3):
         st = sa.default_settings()
         st.num_devices = ndev
