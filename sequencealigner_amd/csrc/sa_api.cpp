@@ -237,7 +237,9 @@ int ensure_triangular(sa_ctx* c) {
         len_sorted[slot] = c->len[s];
         const uint8_t* src = c->slots_host.data() + (size_t)s * c->lslot;
         for (uint32_t i = 0; i < c->len[s]; i++) codes_t[(size_t)i * c->npad + slot] = src[i];
-        if (!lng) memcpy(&codes_s[(size_t)slot * SA_LP], src, c->len[s]);
+        if (!lng)      // 16-byte pieces, piece-major: piece j of bucket-order slot q at (j * npad + q) * 16
+            for (uint32_t i = 0; i < c->len[s]; i += 16)
+                memcpy(&codes_s[((size_t)(i >> 4) * c->npad + slot) * 16], src + i, std::min<uint32_t>(16, c->len[s] - i));
         running[b]++;
         memcpy(&c->cursor[(size_t)s * nb], running.data(), nb * sizeof(uint32_t));
     }

@@ -84,7 +84,8 @@ typedef struct {
     const uint8_t* codes_fo;     /* [N][64] residue codes padded with SA_PAD_CODE, file order */
     const uint16_t* len_fo;      /* [N] */
     const uint8_t* codes_t;      /* [64 pos][npad] residue codes in bucket order, position-major */
-    const uint8_t* codes_s;      /* [npad][64] the same codes, one 64-byte slot per bucket-order slot */
+    const uint8_t* codes_s;      /* [4][npad][16] the same codes in 16-byte pieces, piece-major: the lanes of a wave (consecutive
+                                    bucket-order slots) read a piece as 1 KiB in a row, and only the pieces their sequences reach */
     const uint32_t* fi_sorted;   /* [npad] file index of each bucket-order slot */
     const uint16_t* len_sorted;  /* [npad] */
     const uint32_t* bucket_base; /* [nb+1] first bucket-order slot of each bucket */

@@ -250,10 +250,10 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_kernel(const Sa
             uint32_t bw[16];
             if (MODE == SA_MODE_TRI) {
                 // the lane's second sequence, 64 residue codes in 16 registers
-                const uint4* src = reinterpret_cast<const uint4*>(P.codes_s + (size_t)sidx_l * SA_LP);
+                const uint4* src = reinterpret_cast<const uint4*>(P.codes_s) + sidx_l;
 #pragma unroll
                 for (int q4 = 0; q4 < 4; q4++) {
-                    const uint4 v = src[q4];
+                    const uint4 v = src[(size_t)q4 * P.npad];
                     bw[4 * q4 + 0] = v.x; bw[4 * q4 + 1] = v.y; bw[4 * q4 + 2] = v.z; bw[4 * q4 + 3] = v.w;
                 }
             } else {

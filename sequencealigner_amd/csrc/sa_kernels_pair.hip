@@ -125,15 +125,16 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
             // before: requests complete in order.)
             uint8_t* const qres = reinterpret_cast<uint8_t*>(stage + lane * SD + 2);
             {
-                const uint4* src = reinterpret_cast<const uint4*>(P.codes_s + (size_t)sidx * SA_LP);
+                const uint4* src = reinterpret_cast<const uint4*>(P.codes_s) + sidx;
                 uint2* dst = reinterpret_cast<uint2*>(qres);
                 // only the 16-byte pieces that hold residues of the wave's longest second sequence (plus the one
-                // the row loop's look-ahead may touch): slots are fetched from beyond the L2 in 32-byte sectors
+                // the row loop's look-ahead may touch); the pieces are stored piece-major, so what is not requested
+                // is not fetched either (64-byte slots cost 55 GB of reads per launch of 50 000 peptides)
                 const int nq = min(4, (maxlen >> 4) + 1);
 #pragma unroll
                 for (int q4 = 0; q4 < 4; q4++) {
                     if (q4 < nq) {
-                        const uint4 v = src[q4];
+                        const uint4 v = src[(size_t)q4 * P.npad];
                         dst[2 * q4] = make_uint2(v.x, v.y);
                         dst[2 * q4 + 1] = make_uint2(v.z, v.w);
                     }
