@@ -205,13 +205,17 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_kernel(const Sa
                 for (int r = 0; r < maxlen; r += 2) {
                     // residues two rows ahead: their latency is covered by two rows of arithmetic
                     const int b2 = residue(r + 2), b3 = residue(r + 3);
+                    // the rows' end tests compare this copy of gend where they stand (hoisted out of the loop each
+                    // holds a pair of scalar registers and comes back as vector instructions)
+                    int gr = gend;
+                    asm volatile("" : "+s"(gr));
                     if (r < lenq) {
-                        fill_row_tri_tag(R, Q, gend, 1, 0, prof + b0 * SA_PROF_STRIDE, prof + b1 * SA_PROF_STRIDE, sc0, sc0,
+                        fill_row_tri_tag(R, Q, gr, 1, 0, prof + b0 * SA_PROF_STRIDE, prof + b1 * SA_PROF_STRIDE, sc0, sc0,
                                          e0, e1, e2, e3);
                         store_dirs(r);
                     }
                     if (r + 1 < lenq) {
-                        fill_row_tri_tag(Q, R, gend, 1, 0, prof + b1 * SA_PROF_STRIDE, prof + b2 * SA_PROF_STRIDE, sc0, sc0,
+                        fill_row_tri_tag(Q, R, gr, 1, 0, prof + b1 * SA_PROF_STRIDE, prof + b2 * SA_PROF_STRIDE, sc0, sc0,
                                          e0, e1, e2, e3);
                         store_dirs(r + 1);
                     }
