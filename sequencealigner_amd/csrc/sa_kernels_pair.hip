@@ -142,15 +142,17 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
             }
             // Direction rows, one pair at a time: 16-bit pieces of eight columns, n16 per row and lane; the rows of the
             // low halves first, then those of the high halves (layout and register form: traceback_pk).
+            // (an odd piece that holds only the row's last group of four columns is stored as its upper byte)
             const int n16 = (gend + 1) >> 1;
-            const int row_bytes = 128 * n16;
+            const int row_bytes = 256 * (n16 >> 1) + ((n16 & 1) ? ((gend & 1) ? 64 : 128) : 0);
             const int half_off = SA_LP * row_bytes;
             // GEND = the row's length in groups as a constant: what is stored, and how, is then decided at compile time
             auto store_dirs = [&](int r, auto GC) {
                 constexpr int GEND = decltype(GC)::value;
-                constexpr int N16 = (GEND + 1) / 2, WD = N16 / 2, ODD = N16 & 1;
-                const int row_off = r * (128 * N16);
-                const int hoff = SA_LP * (128 * N16) + row_off;
+                constexpr int N16 = (GEND + 1) / 2, WD = N16 / 2, ODD = N16 & 1, PB = (GEND & 1) ? 1 : 2;
+                constexpr int ROW_BYTES = 256 * WD + 64 * PB * ODD;
+                const int row_off = r * ROW_BYTES;
+                const int hoff = SA_LP * ROW_BYTES + row_off;
                 uint32_t lo[4], hi[4];
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
@@ -185,9 +187,14 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
                 if constexpr (ODD == 1) {
                     // the row's last eight columns: the word's two halves are the two pairs' pieces as they stand
                     const uint32_t w = e[2 * WD < NACC ? 2 * WD : 0];
-                    const int piece_lane = 256 * WD + lane * 2;
-                    __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(w & 0xffffu), spill, piece_lane, row_off, 0);
-                    __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(w >> 16), spill, piece_lane, hoff, 0);
+                    const int piece_lane = 256 * WD + lane * PB;
+                    if constexpr (PB == 2) {
+                        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(w & 0xffffu), spill, piece_lane, row_off, 0);
+                        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(w >> 16), spill, piece_lane, hoff, 0);
+                    } else {       // four columns: the upper byte of each pair's piece
+                        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)((w >> 8) & 0xffu), spill, piece_lane, row_off, 0);
+                        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(w >> 24), spill, piece_lane, hoff, 0);
+                    }
                 }
             };
 
@@ -251,18 +258,23 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
                 const int mlen = __builtin_amdgcn_readfirstlane(wave_max(lq));
                 const int base = half ? half_off : 0;
                 int matches = 0, gaps = 0;
-#define SA_TRACEBACK(WD, ODD)                                                                              \
-    traceback_pk<WD, ODD, PROF_BYTES + 4, SD>(lane, mlen, lq, lenp, spill, base, bw,                       \
-                                              stage + lane * SD, matches, gaps)
-                switch (n16) {
-                    case 1: SA_TRACEBACK(0, 1); break;
-                    case 2: SA_TRACEBACK(1, 0); break;
-                    case 3: SA_TRACEBACK(1, 1); break;
-                    case 4: SA_TRACEBACK(2, 0); break;
-                    case 5: SA_TRACEBACK(2, 1); break;
-                    case 6: SA_TRACEBACK(3, 0); break;
-                    case 7: SA_TRACEBACK(3, 1); break;
-                    default: if constexpr (NG > 13) SA_TRACEBACK(4, 0); break;
+#define SA_TRACEBACK(WD, ODD, PB)                                                                          \
+    traceback_pk<WD, ODD, PB, PROF_BYTES + 4, SD>(lane, mlen, lq, lenp, spill, base, bw,                   \
+                                                  stage + lane * SD, matches, gaps)
+                switch (gend) {          // groups of four columns -> dwords, odd piece, bytes of the piece
+                    case 1: SA_TRACEBACK(0, 1, 1); break;
+                    case 2: SA_TRACEBACK(0, 1, 2); break;
+                    case 3: case 4: SA_TRACEBACK(1, 0, 2); break;
+                    case 5: SA_TRACEBACK(1, 1, 1); break;
+                    case 6: SA_TRACEBACK(1, 1, 2); break;
+                    case 7: case 8: SA_TRACEBACK(2, 0, 2); break;
+                    case 9: SA_TRACEBACK(2, 1, 1); break;
+                    case 10: SA_TRACEBACK(2, 1, 2); break;
+                    case 11: case 12: SA_TRACEBACK(3, 0, 2); break;
+                    case 13: SA_TRACEBACK(3, 1, 1); break;
+                    default:
+                        if constexpr (NG > 13) { if (gend == 14) SA_TRACEBACK(3, 1, 2); else SA_TRACEBACK(4, 0, 2); }
+                        break;
                 }
 #undef SA_TRACEBACK
                 SA_PHASE(4);

@@ -221,7 +221,9 @@ __device__ __forceinline__ uint32_t sa_tb_elem(const WORDS& d, const int i) {
 // more (a third of the row requests' bytes on the bench set), and likewise the pieces.
 // In registers the row is W = WD + ODD dwords, highest columns in dword 0: the piece shifted to the upper half of
 // dword 0 (its lower half stands for columns past the row's end), then the higher area's dwords, then the lower's.
-template <int WD, int ODD, int PCOL_LDS_OFFSET, int STAGE_DWORDS>
+// PB: bytes of a lane's odd piece in memory, 2 or 1 -- when the row's last group of four columns stands alone in the
+// piece, only the piece's upper byte is stored.
+template <int WD, int ODD, int PB, int PCOL_LDS_OFFSET, int STAGE_DWORDS>
 __device__ __forceinline__ void traceback_pk(const int lane, const int maxlen, const int lenq, const int lenp,
                                              const __amdgpu_buffer_rsrc_t spill, const int base_off,
                                              const uint32_t (&bw)[16],
@@ -229,7 +231,7 @@ __device__ __forceinline__ void traceback_pk(const int lane, const int maxlen, c
     constexpr int W = WD + ODD;
     constexpr int WH = WD / 2, WL = WD - WH;
     constexpr int NS = W <= 1 ? SA_TB_SETS_W1 : W == 2 ? SA_TB_SETS_W2 : W == 3 ? SA_TB_SETS_W3 : SA_TB_SETS_W4;   // register sets
-    constexpr int ROW_BYTES = 64 * (4 * WD + 2 * ODD);
+    constexpr int ROW_BYTES = 64 * (4 * WD + PB * ODD);
     typedef typename SaDirWords<WL ? WL : 1>::type low_t;
     typedef typename SaDirWords<WH ? WH : 1>::type high_t;
     struct Chunk { low_t lo[4]; high_t hi[4]; uint32_t piece[4]; };
@@ -237,7 +239,7 @@ __device__ __forceinline__ void traceback_pk(const int lane, const int maxlen, c
     uint32_t s = lenq > 0 ? 2u * (uint32_t)lenp + 1u : 0u, matches = 0, ups = 0;
     const int high_off = lane * WH * 4;
     const int low_off = 256 * WH + lane * WL * 4;
-    const int piece_off = 256 * WD + lane * 2;
+    const int piece_off = 256 * WD + lane * PB;
 
     // Rows of chunk ch; the state s = 2 * (column + 1) + 1 only falls, so what no lane needs now it will not need later.
     // The first request into each register set asks for everything, so that every register holds a row's bits.
@@ -255,11 +257,14 @@ __device__ __forceinline__ void traceback_pk(const int lane, const int maxlen, c
                 if constexpr (WH == 2) ck.hi[k] = __builtin_amdgcn_raw_buffer_load_b64(spill, high_off, row_off, 0);
                 else if constexpr (WH == 1) ck.hi[k] = __builtin_amdgcn_raw_buffer_load_b32(spill, high_off, row_off, 0);
             }
-            if (need_piece) ck.piece[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(spill, piece_off, row_off, 0);
+            if (need_piece) {
+                if constexpr (PB == 2) ck.piece[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(spill, piece_off, row_off, 0);
+                else ck.piece[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(spill, piece_off, row_off, 0);
+            }
         }
     };
     // dword m of row k of a chunk in the register form described above
-#define SA_TB_WORD(m) ((ODD == 1 && (m) == 0) ? ck.piece[k] << 16                                                   \
+#define SA_TB_WORD(m) ((ODD == 1 && (m) == 0) ? ck.piece[k] << (32 - 8 * PB)                                                   \
                        : ((m) - ODD < WH) ? sa_tb_elem<WH>(ck.hi[k], ((m) - ODD < WH && (m) >= ODD) ? (m) - ODD : 0) \
                                           : sa_tb_elem<WL>(ck.lo[k], ((m) - ODD >= WH && (m) - ODD - WH < WL) ? (m) - ODD - WH : 0))
 
