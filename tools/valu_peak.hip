@@ -50,6 +50,20 @@ constexpr int CHAINS = 8;
 #define K_BFI 31
 #define K_CELL_PK 32
 #define K_CELL_PK3 33
+#define K_LSHR64 34
+#define K_FFBL 35
+#define K_ADDCLAMP 36
+#define K_OR 37
+#define K_XOR 38
+#define K_LSHL 39
+#define K_NOT 40
+#define K_BCNT 41
+#define K_SUBLIT 42
+#define K_CMPSDWA 43
+#define K_MIN3 44
+#define K_MED3 45
+#define K_ANDLIT 46
+#define K_LSHRV 47
 
 template <int KIND>
 __global__ void __launch_bounds__(256) k_valu(unsigned* out, unsigned long long* cyc, unsigned seed) {
@@ -122,6 +136,20 @@ __global__ void __launch_bounds__(256) k_valu(unsigned* out, unsigned long long*
                 a[k] = h;
             }
             if (KIND == K_ALIGNBIT) asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(a[k]) : "v"(b));
+            if (KIND == K_LSHR64) { unsigned long long q = ((unsigned long long)f[k] << 32) | a[k]; asm volatile("v_lshrrev_b64 %0, %1, %0" : "+v"(q) : "v"(b)); a[k] = (unsigned)q; f[k] = (unsigned)(q >> 32); }
+            if (KIND == K_FFBL) asm volatile("v_ffbl_b32 %0, %0" : "+v"(a[k]));
+            if (KIND == K_ADDCLAMP) asm volatile("v_add_u32 %0, %0, 32 clamp" : "+v"(a[k]));
+            if (KIND == K_OR) asm volatile("v_or_b32 %0, %0, %1" : "+v"(a[k]) : "v"(b));
+            if (KIND == K_XOR) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[k]) : "v"(b));
+            if (KIND == K_LSHL) asm volatile("v_lshlrev_b32 %0, 3, %0" : "+v"(a[k]));
+            if (KIND == K_NOT) asm volatile("v_not_b32 %0, %0" : "+v"(a[k]));
+            if (KIND == K_BCNT) asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a[k]) : "v"(b));
+            if (KIND == K_SUBLIT) asm volatile("v_subrev_u32 %0, 0x1010101, %0" : "+v"(a[k]));
+            if (KIND == K_CMPSDWA) asm volatile("v_cmp_eq_u32_sdwa vcc, %0, %1 src0_sel:DWORD src1_sel:BYTE_2" : : "v"(a[k]), "v"(b) : "vcc");
+            if (KIND == K_MIN3) asm volatile("v_min3_u32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));
+            if (KIND == K_MED3) asm volatile("v_med3_i32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));
+            if (KIND == K_ANDLIT) asm volatile("v_and_b32 %0, 0x7f7f7f7f, %0" : "+v"(a[k]));
+            if (KIND == K_LSHRV) asm volatile("v_lshrrev_b32 %0, %1, %0" : "+v"(a[k]) : "v"(b));
             if (KIND == K_ANDOR) asm volatile("v_and_or_b32 %0, %0, %1, 1" : "+v"(a[k]) : "v"(b));
             if (KIND == K_PKMAX3F) asm volatile("v_pk_maximum3_f16 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));
             if (KIND == K_BFI) asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(a[k]) : "v"(b), "v"(c));
@@ -228,6 +256,23 @@ int main() {
     printf("device %s CUs=%d clock=%.3f GHz\n", p.name, ncu, p.clockRate / 1e6);
     unsigned* d_out; CHECK(hipMalloc(&d_out, sizeof(unsigned) * ncu * 4 * 256));
     unsigned long long* d_cyc; CHECK(hipMalloc(&d_cyc, 8 * ncu * 4 * 4));
+    if (getenv("VALU_PEAK_WALK")) {
+        run<K_LSHR64>("v_lshrrev_b64", 1, d_out, d_cyc, ncu);
+        run<K_FFBL>("v_ffbl_b32", 1, d_out, d_cyc, ncu);
+        run<K_ADDCLAMP>("v_add_u32 clamp", 1, d_out, d_cyc, ncu);
+        run<K_OR>("v_or_b32", 1, d_out, d_cyc, ncu);
+        run<K_XOR>("v_xor_b32", 1, d_out, d_cyc, ncu);
+        run<K_LSHL>("v_lshlrev_b32", 1, d_out, d_cyc, ncu);
+        run<K_LSHRV>("v_lshrrev_b32 (register amount)", 1, d_out, d_cyc, ncu);
+        run<K_NOT>("v_not_b32", 1, d_out, d_cyc, ncu);
+        run<K_BCNT>("v_bcnt_u32_b32", 1, d_out, d_cyc, ncu);
+        run<K_SUBLIT>("v_subrev_u32 literal", 1, d_out, d_cyc, ncu);
+        run<K_ANDLIT>("v_and_b32 literal", 1, d_out, d_cyc, ncu);
+        run<K_CMPSDWA>("v_cmp_eq_u32_sdwa", 1, d_out, d_cyc, ncu);
+        run<K_MIN3>("v_min3_u32", 1, d_out, d_cyc, ncu);
+        run<K_MED3>("v_med3_i32", 1, d_out, d_cyc, ncu);
+        return 0;
+    }
     run<K_CELL_SIGN>("cell: add,max3,2x(sub,alignbit) (6)", 6, d_out, d_cyc, ncu);
     run<K_CELL_TAG>("cell: add,max3,alignbit,and,or (5)", 5, d_out, d_cyc, ncu);
     run<K_ALIGNBIT>("v_alignbit_b32", 1, d_out, d_cyc, ncu);
