@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
                 }
                 // Highest columns first; the dwords of the higher columns (WH of them) of all lanes stand in front
                 // of those of the lower columns (see traceback_pk, which stops requesting the former).
-                constexpr int WH = WD / 2, WL = WD - WH;
+                constexpr int WH = SA_DIR_WH(WD), WL = WD - WH;
                 const int high_lane = lane * (WH * 4), low_lane = 256 * WH + lane * (WL * 4);
                 if constexpr (WH == 2) {
                     const sa_u32x2 a = {lo[WD - 1], lo[WD - 2]}, b = {hi[WD - 1], hi[WD - 2]};
@@ -176,7 +176,15 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
                     __builtin_amdgcn_raw_buffer_store_b32(lo[WD - 1], spill, high_lane, row_off, 0);
                     __builtin_amdgcn_raw_buffer_store_b32(hi[WD - 1], spill, high_lane, hoff, 0);
                 }
-                if constexpr (WL == 2) {
+                if constexpr (WL == 4) {
+                    const sa_u32x4 a = {lo[3], lo[2], lo[1], lo[0]}, b = {hi[3], hi[2], hi[1], hi[0]};
+                    __builtin_amdgcn_raw_buffer_store_b128(a, spill, low_lane, row_off, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(b, spill, low_lane, hoff, 0);
+                } else if constexpr (WL == 3) {
+                    const sa_u32x3 a = {lo[2], lo[1], lo[0]}, b = {hi[2], hi[1], hi[0]};
+                    __builtin_amdgcn_raw_buffer_store_b96(a, spill, low_lane, row_off, 0);
+                    __builtin_amdgcn_raw_buffer_store_b96(b, spill, low_lane, hoff, 0);
+                } else if constexpr (WL == 2) {
                     const sa_u32x2 a = {lo[1], lo[0]}, b = {hi[1], hi[0]};
                     __builtin_amdgcn_raw_buffer_store_b64(a, spill, low_lane, row_off, 0);
                     __builtin_amdgcn_raw_buffer_store_b64(b, spill, low_lane, hoff, 0);

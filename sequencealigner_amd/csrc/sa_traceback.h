@@ -200,6 +200,12 @@ __device__ __forceinline__ uint32_t sa_ctz64_min(uint64_t x, uint32_t cap) { // 
 #define SA_TB_SETS_W3 2
 #define SA_TB_SETS_W4 2
 #endif
+// Dwords of a row that go to the area of the higher columns.  A row of two dwords is not split: as one 8-byte
+// access per lane, sixteen lanes fill a 128-byte line, where two 4-byte accesses each return to a line whose
+// first half is still on its way (102.7-103.1 -> 102.1-102.2 ms on one box, with 2 % more bytes read).
+#ifndef SA_DIR_WH
+#define SA_DIR_WH(WD) ((WD) >= 3 ? (WD) / 2 : 0)
+#endif
 template <int W> struct SaDirWords;
 template <> struct SaDirWords<1> { typedef uint32_t type; };
 template <> struct SaDirWords<2> { typedef sa_u32x2 type; };
@@ -215,7 +221,7 @@ __device__ __forceinline__ uint32_t sa_tb_elem(const WORDS& d, const int i) {
 
 // A direction row of one pair is 8-column pieces of 16 bits, N16 = ceil(columns / 8) of them, that is WD = N16 / 2
 // dwords and, for odd N16 (ODD = 1), one more piece with the row's last eight columns.  In memory a row of the wave is
-// three areas: the WH = WD / 2 dwords of the higher columns of every lane (64 lanes side by side), the WL = WD - WH
+// three areas: the WH = SA_DIR_WH(WD) dwords of the higher columns of every lane (64 lanes side by side), the WL = WD - WH
 // dwords of the lower columns, the pieces (128 bytes).  The walk moves towards column 0 and never looks at a column
 // above the one it stands in: once every lane of the wave has left the higher columns their area is not requested any
 // more (a third of the row requests' bytes on the bench set), and likewise the pieces.
@@ -229,7 +235,7 @@ __device__ __forceinline__ void traceback_pk(const int lane, const int maxlen, c
                                              const uint32_t (&bw)[16],
                                              uint32_t* __restrict__ stage_rec, int& matches_out, int& gaps_out) {
     constexpr int W = WD + ODD;
-    constexpr int WH = WD / 2, WL = WD - WH;
+    constexpr int WH = SA_DIR_WH(WD), WL = WD - WH;
     constexpr int NS = W <= 1 ? SA_TB_SETS_W1 : W == 2 ? SA_TB_SETS_W2 : W == 3 ? SA_TB_SETS_W3 : SA_TB_SETS_W4;   // register sets
     constexpr int ROW_BYTES = 64 * (4 * WD + PB * ODD);
     typedef typename SaDirWords<WL ? WL : 1>::type low_t;
@@ -251,7 +257,9 @@ __device__ __forceinline__ void traceback_pk(const int lane, const int maxlen, c
         for (int k = 0; k < 4; k++) {
             const int r = min(4 * ch + k, maxlen - 1);   // wave-uniform
             const int row_off = base_off + r * ROW_BYTES;
-            if constexpr (WL == 2) ck.lo[k] = __builtin_amdgcn_raw_buffer_load_b64(spill, low_off, row_off, 0);
+            if constexpr (WL == 4) ck.lo[k] = __builtin_amdgcn_raw_buffer_load_b128(spill, low_off, row_off, 0);
+            else if constexpr (WL == 3) ck.lo[k] = __builtin_amdgcn_raw_buffer_load_b96(spill, low_off, row_off, 0);
+            else if constexpr (WL == 2) ck.lo[k] = __builtin_amdgcn_raw_buffer_load_b64(spill, low_off, row_off, 0);
             else if constexpr (WL == 1) ck.lo[k] = __builtin_amdgcn_raw_buffer_load_b32(spill, low_off, row_off, 0);
             if (need_high) {
                 if constexpr (WH == 2) ck.hi[k] = __builtin_amdgcn_raw_buffer_load_b64(spill, high_off, row_off, 0);
