@@ -239,6 +239,9 @@ def few_pairs_measurement(sa, synth, device):
     return out
 
 
+MIX_PEAK_TLANE = 38.49
+
+
 def counter_rates(rec, k_ms):
     """Rates from the per-launch counter totals of profiles/ and the kernel time measured in this run."""
     sec = k_ms * 1e-3
@@ -246,7 +249,11 @@ def counter_rates(rec, k_ms):
     if rec.get("valu_wave_insts"):
         lane = rec["valu_wave_insts"] * 64
         out["issue"] = {"lane_insts_per_launch": lane, "achieved": round(lane / sec / 1e12, 2), "peak": round(PEAK_TIOPS, 2),
-                        "unit": "T lane-instr/s", "frac": round(lane / sec / 1e12 / PEAK_TIOPS, 4)}
+                        "unit": "T lane-instr/s", "frac": round(lane / sec / 1e12 / PEAK_TIOPS, 4),
+                        # the packed kernels' column-pair block issued back to back with no memory access, four waves per
+                        # SIMD (tools/valu_peak.hip, profiles/r02_valu_cell_block_rates.txt): the chip lowers its clock to
+                        # 1.94 GHz under that stream, so this, not the 2.4 GHz line, is what the instruction mix can reach
+                        "mix_peak": MIX_PEAK_TLANE, "mix_frac": round(lane / sec / 1e12 / MIX_PEAK_TLANE, 4)}
     if rec.get("lds_bytes"):
         out["lds"] = {"bytes_per_launch": rec["lds_bytes"], "achieved": round(rec["lds_bytes"] / sec / 1e12, 2),
                       "peak": LDS_PEAK_TBS, "unit": "TB/s", "frac": round(rec["lds_bytes"] / sec / 1e12 / LDS_PEAK_TBS, 4),

@@ -19,6 +19,19 @@ __device__ __forceinline__ int wave_max(int v) {
     for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
     return v;
 }
+// Maximum of a value that is >= 0 in every lane, as a wave-uniform number, all 64 lanes active.  A max-scan along the
+// rows of 16 lanes by DPP shifts, then lane 15 of rows 0 and 2 handed to rows 1 and 3 and lane 31 to the upper half:
+// lane 63 ends with the maximum.  Lanes without a source take 0.  Ten vector instructions and no LDS traffic against
+// six ds_bpermute exchanges with their address arithmetic.
+__device__ __forceinline__ int wave_max_nonneg(int v) {
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false));   // row_shr:1
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false));   // row_shr:2
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false));   // row_shr:4
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false));   // row_shr:8
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false));   // row_bcast:15 into rows 1 and 3
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false));   // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
 __device__ __forceinline__ int wave_min(int v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));

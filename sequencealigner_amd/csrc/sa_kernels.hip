@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_kernel(const Sa
                 const uint32_t fiq = P.fi_sorted[sidx];
                 lenq = active ? P.len_sorted[sidx] : 0;
                 lenp = lenp_u;
-                maxlen = __builtin_amdgcn_readfirstlane(wave_max(lenq));
+                maxlen = wave_max_nonneg(lenq);
                 gend = (lenp_u + 3) >> 2;
                 rel = fiq - item.p - 1;
                 brow = P.codes_t + sidx;
@@ -147,8 +147,8 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_kernel(const Sa
                 const uint32_t s2 = s1 + 1;
                 lenp = P.len_fo[s1];
                 lenq = active ? P.len_fo[s2] : 0;
-                maxlen = __builtin_amdgcn_readfirstlane(wave_max(lenq));
-                gend = (__builtin_amdgcn_readfirstlane(wave_max(lenp)) + 3) >> 2;
+                maxlen = wave_max_nonneg(lenq);
+                gend = (wave_max_nonneg(lenp) + 3) >> 2;
                 rel = lane;
                 acol = P.codes_fo + (size_t)s1 * SA_LP;
                 brow = P.codes_fo + (size_t)s2 * SA_LP;

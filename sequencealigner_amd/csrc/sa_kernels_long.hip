@@ -110,14 +110,14 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_kernel(const SaPep
                 const uint32_t s2 = s1 + 1;
                 lenp = P.len_fo[s1];
                 lenq = active ? P.len_fo[s2] : 0;
-                maxlenp = __builtin_amdgcn_readfirstlane(wave_max(active ? lenp : 1));
+                maxlenp = wave_max_nonneg(active ? lenp : 1);
                 rel = lane;
                 acol = P.codes_fo + (size_t)s1 * P.lslot;
                 brow = P.codes_fo + (size_t)s2 * P.lslot;
                 bslot = brow;
                 bstep = 1;
             }
-            maxlen = __builtin_amdgcn_readfirstlane(wave_max(lenq));
+            maxlen = wave_max_nonneg(lenq);
             const int nstrips = (maxlenp + 63) >> 6;
             const int gend_last = ((maxlenp - 64 * (nstrips - 1)) + 3) >> 2;
             const int last_row = (int)rows_cap - 1;

@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_pair_kernel(const 
             const int lenq = active ? (int)P.len_sorted[sidx] : 0;
             const bool active2 = active && has2 && fiq > p2;
             const uint8_t* const bslot = P.codes_fo + (size_t)fiq * P.lslot;      // sequence 2 as one padded slot
-            const int maxlen = __builtin_amdgcn_readfirstlane(wave_max(lenq));
+            const int maxlen = wave_max_nonneg(lenq);
             SA_PHASE(2);
 
             // -------------------------------------------------------------- fill
@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_pair_kernel(const 
                 if (!__any(act)) continue;
                 const int lenp = half ? lenp2 : lenp1;
                 const int lq = act ? lenq : 0;
-                const int mlen = __builtin_amdgcn_readfirstlane(wave_max(lq));
+                const int mlen = wave_max_nonneg(lq);
                 const uint32_t* hd = dirs + (half ? half_dirs : 0);
                 const uint8_t* ps = pseq + (half ? P.lslot : 0);
                 uint8_t* rec = (half ? out_row2 : out_row1) + (size_t)(fiq - (half ? p2 : p1) - 1) * P.stride;

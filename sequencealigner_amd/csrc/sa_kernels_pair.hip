@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
             const uint32_t fiq = P.fi_sorted[sidx];
             const int lenq = active ? (int)P.len_sorted[sidx] : 0;
             const bool active2 = active && has2 && fiq > p2;
-            const int maxlen = __builtin_amdgcn_readfirstlane(wave_max(lenq));
+            const int maxlen = wave_max_nonneg(lenq);
             SA_PHASE(2);
 
             // -------------------------------------------------------------- fill
@@ -269,25 +269,27 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
                 const int lq = act ? lenq : 0;
                 reinterpret_cast<uint16_t*>(pcol + 4)[lane] = (uint16_t)(0xff00u | pcol[192 + 64 * half + lane]);
                 __syncthreads();
-                const int mlen = __builtin_amdgcn_readfirstlane(wave_max(lq));
+                const int mlen = wave_max_nonneg(lq);
                 const int base = half ? half_off : 0;
                 int matches = 0, gaps = 0;
-#define SA_TRACEBACK(WD, ODD, PB)                                                                          \
-    traceback_pk<WD, ODD, PB, PROF_BYTES + 4, SD>(lane, mlen, lq, lenp, spill, base, bw,                   \
-                                                  stage + lane * SD, matches, gaps)
+#define SA_TRACEBACK(WD, ODD, PB, CLAMP)                                                                   \
+    traceback_pk<WD, ODD, PB, CLAMP, PROF_BYTES + 4, SD>(lane, mlen, lq, lenp, spill, base, bw,            \
+                                                         stage + lane * SD, matches, gaps)
                 switch (gend) {          // groups of four columns -> dwords, odd piece, bytes of the piece
-                    case 1: SA_TRACEBACK(0, 1, 1); break;
-                    case 2: SA_TRACEBACK(0, 1, 2); break;
-                    case 3: case 4: SA_TRACEBACK(1, 0, 2); break;
-                    case 5: SA_TRACEBACK(1, 1, 1); break;
-                    case 6: SA_TRACEBACK(1, 1, 2); break;
-                    case 7: case 8: SA_TRACEBACK(2, 0, 2); break;
-                    case 9: SA_TRACEBACK(2, 1, 1); break;
-                    case 10: SA_TRACEBACK(2, 1, 2); break;
-                    case 11: case 12: SA_TRACEBACK(3, 0, 2); break;
-                    case 13: SA_TRACEBACK(3, 1, 1); break;
+                    case 1: SA_TRACEBACK(0, 1, 1, false); break;
+                    case 2: SA_TRACEBACK(0, 1, 2, false); break;
+                    case 3: SA_TRACEBACK(1, 0, 2, false); break;
+                    case 4: SA_TRACEBACK(1, 0, 2, true); break;
+                    case 5: SA_TRACEBACK(1, 1, 1, false); break;
+                    case 6: SA_TRACEBACK(1, 1, 2, false); break;
+                    case 7: SA_TRACEBACK(2, 0, 2, false); break;
+                    case 8: SA_TRACEBACK(2, 0, 2, true); break;
+                    case 9: SA_TRACEBACK(2, 1, 1, true); break;
+                    case 10: SA_TRACEBACK(2, 1, 2, true); break;
+                    case 11: case 12: SA_TRACEBACK(3, 0, 2, true); break;
+                    case 13: SA_TRACEBACK(3, 1, 1, true); break;
                     default:
-                        if constexpr (NG > 13) { if (gend == 14) SA_TRACEBACK(3, 1, 2); else SA_TRACEBACK(4, 0, 2); }
+                        if constexpr (NG > 13) { if (gend == 14) SA_TRACEBACK(3, 1, 2, true); else SA_TRACEBACK(4, 0, 2, true); }
                         break;
                 }
 #undef SA_TRACEBACK
@@ -300,18 +302,38 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
                 // ------------------------------------------- records, 16 B per lane store
                 uint8_t* const out_row = half ? out_row2 : out_row1;
                 const uint32_t rel = fiq - (half ? p2 : p1) - 1;
-                for (uint32_t id = lane; id < 64 * cpr; id += 64) {
-                    const uint32_t rec = id / cpr, ch = id - rec * cpr;
-                    const uint32_t rrel = __shfl(rel, rec, 64);
-                    const int ract = __shfl((int)act, rec, 64);
-                    if (ract) {
-                        // written once and not read again on the device: kept out of the way of the direction rows
-                        // (two 8-byte reads: a lane's part of the staging area is 8-byte aligned)
-                        const uint2 va = *reinterpret_cast<const uint2*>(stage + rec * SD + ch * 4);
-                        uint2 vb = make_uint2(0u, 0u);      // bytes 72 .. 79 of an 80-byte record: padding
-                        if (ch * 4 + 2 < (uint32_t)SD) vb = *reinterpret_cast<const uint2*>(stage + rec * SD + ch * 4 + 2);
-                        const sa_u32x4 v = {va.x, va.y, vb.x, vb.y};
-                        __builtin_nontemporal_store(v, reinterpret_cast<sa_u32x4*>(out_row + (uint64_t)rrel * P.stride + ch * 16));
+                if (cpr == 4) {
+                    // 64-byte records (no sequence above 56 residues): four lanes per record, sixteen records per round; the
+                    // record's place in the row and whether its pair exists come from its lane in one exchange, and the
+                    // staging addresses differ from round to round by a constant.  (With the record index and chunk found
+                    // by a division by a run-time chunk count, this loop was 280 of a task's 5 700 vector instructions.)
+                    const uint32_t relact = act ? rel : 0xffffffffu;
+                    const uint32_t* const src = stage + (lane >> 2) * SD + (lane & 3) * 4;
+                    uint8_t* const dst = out_row + (lane & 3) * 16;
+#pragma unroll
+                    for (int round = 0; round < 4; round++) {
+                        const uint32_t rrel = __shfl(relact, (lane >> 2) + 16 * round, 64);
+                        if (rrel != 0xffffffffu) {
+                            const uint2 va = *reinterpret_cast<const uint2*>(src + round * 16 * SD);
+                            const uint2 vb = *reinterpret_cast<const uint2*>(src + round * 16 * SD + 2);
+                            const sa_u32x4 v = {va.x, va.y, vb.x, vb.y};
+                            __builtin_nontemporal_store(v, reinterpret_cast<sa_u32x4*>(dst + (uint64_t)rrel * 64));
+                        }
+                    }
+                } else {
+                    for (uint32_t id = lane; id < 64 * cpr; id += 64) {
+                        const uint32_t rec = id / cpr, ch = id - rec * cpr;
+                        const uint32_t rrel = __shfl(rel, rec, 64);
+                        const int ract = __shfl((int)act, rec, 64);
+                        if (ract) {
+                            // written once and not read again on the device: kept out of the way of the direction rows
+                            // (two 8-byte reads: a lane's part of the staging area is 8-byte aligned)
+                            const uint2 va = *reinterpret_cast<const uint2*>(stage + rec * SD + ch * 4);
+                            uint2 vb = make_uint2(0u, 0u);      // bytes 72 .. 79 of an 80-byte record: padding
+                            if (ch * 4 + 2 < (uint32_t)SD) vb = *reinterpret_cast<const uint2*>(stage + rec * SD + ch * 4 + 2);
+                            const sa_u32x4 v = {va.x, va.y, vb.x, vb.y};
+                            __builtin_nontemporal_store(v, reinterpret_cast<sa_u32x4*>(out_row + (uint64_t)rrel * P.stride + ch * 16));
+                        }
                     }
                 }
                 __syncthreads();   // staging area is reused

@@ -229,7 +229,11 @@ __device__ __forceinline__ uint32_t sa_tb_elem(const WORDS& d, const int i) {
 // dword 0 (its lower half stands for columns past the row's end), then the higher area's dwords, then the lower's.
 // PB: bytes of a lane's odd piece in memory, 2 or 1 -- when the row's last group of four columns stands alone in the
 // piece, only the piece's upper byte is stored.
-template <int WD, int ODD, int PB, int PCOL_LDS_OFFSET, int STAGE_DWORDS>
+// CLAMP: the walk's lower bound on L at the left border (see above) is applied.  It is needed only when bit 0 of
+// the window's lowest dword can be set: the window then holds a column in its last place (rows of 16, 32, 48 or 64
+// columns, or a computed padding column there) or is wider than 64 bits.  Everywhere else that bit is 0, the
+// unshifted window at the border has at least two trailing zeros and min(L, s = 1) is 1 by itself.
+template <int WD, int ODD, int PB, bool CLAMP, int PCOL_LDS_OFFSET, int STAGE_DWORDS>
 __device__ __forceinline__ void traceback_pk(const int lane, const int maxlen, const int lenq, const int lenp,
                                              const __amdgpu_buffer_rsrc_t spill, const int base_off,
                                              const uint32_t (&bw)[16],
@@ -309,7 +313,7 @@ __device__ __forceinline__ void traceback_pk(const int lane, const int maxlen, c
                     const uint32_t l0 = sa_ctz64_sat(v0);
                     L = min((upper && lx >= 64u) ? s - 65u + l0 : lx, s);
                 }
-                L = (uint32_t)max((int)L, lo);
+                if constexpr (CLAMP) L = (uint32_t)max((int)L, lo);
                 // t = L & 1 (1 = UP ends the run, 0 = DIAG); rest = s - L (DIAG: 2 * (column consumed + 1) + 1);
                 // a = pcol[rest - 3] | t << 8; matches += (a == residue of row r); s = rest + 3t - 2, that is
                 // s - run - (2 for a DIAG move); byte k of the chunk's word = L.  One block of instructions: the
