@@ -252,26 +252,31 @@ __device__ __forceinline__ void traceback_pk(const int lane, const int maxlen, c
     const int piece_off = 256 * WD + lane * PB;
 
     // Rows of chunk ch; the state s = 2 * (column + 1) + 1 only falls, so what no lane needs now it will not need later.
-    // The first request into each register set asks for everything, so that every register holds a row's bits.
+    // Every call issues the same loads: an area that is not wanted (or a chunk above the first or below the last row)
+    // is asked for at an offset beyond the buffer's size, where the hardware fetches nothing and returns 0.  With a
+    // branch around a request instead, the compiler cannot count the requests that follow a chunk's own and waits for
+    // all of them -- the chunk just requested included -- before it touches a row.
+    constexpr int SA_TB_BEYOND = 0x7ffff000;
     auto load_chunk = [&](int ch, Chunk& ck) {
-        const bool first = ch > ((maxlen - 1) >> 2) - NS;
-        const bool need_high = WH > 0 && (first || __any(s >= 32u * WL + 3u));
-        const bool need_piece = ODD == 1 && (first || __any(s >= 32u * WD + 3u));
+        const bool exists = ch >= 0;
+        const bool need_high = WH > 0 && exists && __any(s >= 32u * WL + 3u);
+        const bool need_piece = ODD == 1 && exists && __any(s >= 32u * WD + 3u);
+        const int lo_at = exists ? low_off : SA_TB_BEYOND;
+        const int hi_at = need_high ? high_off : SA_TB_BEYOND;
+        const int piece_at = need_piece ? piece_off : SA_TB_BEYOND;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const int r = min(4 * ch + k, maxlen - 1);   // wave-uniform
+            const int r = max(min(4 * ch + k, maxlen - 1), 0);   // wave-uniform
             const int row_off = base_off + r * ROW_BYTES;
-            if constexpr (WL == 4) ck.lo[k] = __builtin_amdgcn_raw_buffer_load_b128(spill, low_off, row_off, 0);
-            else if constexpr (WL == 3) ck.lo[k] = __builtin_amdgcn_raw_buffer_load_b96(spill, low_off, row_off, 0);
-            else if constexpr (WL == 2) ck.lo[k] = __builtin_amdgcn_raw_buffer_load_b64(spill, low_off, row_off, 0);
-            else if constexpr (WL == 1) ck.lo[k] = __builtin_amdgcn_raw_buffer_load_b32(spill, low_off, row_off, 0);
-            if (need_high) {
-                if constexpr (WH == 2) ck.hi[k] = __builtin_amdgcn_raw_buffer_load_b64(spill, high_off, row_off, 0);
-                else if constexpr (WH == 1) ck.hi[k] = __builtin_amdgcn_raw_buffer_load_b32(spill, high_off, row_off, 0);
-            }
-            if (need_piece) {
-                if constexpr (PB == 2) ck.piece[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(spill, piece_off, row_off, 0);
-                else ck.piece[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(spill, piece_off, row_off, 0);
+            if constexpr (WL == 4) ck.lo[k] = __builtin_amdgcn_raw_buffer_load_b128(spill, lo_at, row_off, 0);
+            else if constexpr (WL == 3) ck.lo[k] = __builtin_amdgcn_raw_buffer_load_b96(spill, lo_at, row_off, 0);
+            else if constexpr (WL == 2) ck.lo[k] = __builtin_amdgcn_raw_buffer_load_b64(spill, lo_at, row_off, 0);
+            else if constexpr (WL == 1) ck.lo[k] = __builtin_amdgcn_raw_buffer_load_b32(spill, lo_at, row_off, 0);
+            if constexpr (WH == 2) ck.hi[k] = __builtin_amdgcn_raw_buffer_load_b64(spill, hi_at, row_off, 0);
+            else if constexpr (WH == 1) ck.hi[k] = __builtin_amdgcn_raw_buffer_load_b32(spill, hi_at, row_off, 0);
+            if constexpr (ODD == 1) {
+                if constexpr (PB == 2) ck.piece[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(spill, piece_at, row_off, 0);
+                else ck.piece[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(spill, piece_at, row_off, 0);
             }
         }
     };
@@ -349,16 +354,13 @@ __device__ __forceinline__ void traceback_pk(const int lane, const int maxlen, c
     Chunk c[NS];
     const int top = (maxlen - 1) >> 2;
 #pragma unroll
-    for (int j = 0; j < NS - 1; j++)
-        if (top - j >= 0) load_chunk(top - j, c[j]);
+    for (int j = 0; j < NS - 1; j++) load_chunk(top - j, c[j]);
     for (int t = top; t >= 0; t -= NS) {
 #pragma unroll
         for (int j = 0; j < NS; j++) {
             const int ch = t - j;                 // the chunk in set j
-            if (ch >= 0) {
-                if (ch - (NS - 1) >= 0) load_chunk(ch - (NS - 1), c[(j + NS - 1) % NS]);
-                process(ch, c[j]);
-            }
+            load_chunk(ch - (NS - 1), c[(j + NS - 1) % NS]);
+            if (ch >= 0) process(ch, c[j]);
         }
     }
     // body bytes past the last chunk are zero, so that equal inputs give equal records
