@@ -225,6 +225,9 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_pair_kernel(const 
             for (int half = 0; half < 2; half++) {
                 const bool act = half ? active2 : active;
                 if (!__any(act)) continue;
+#ifdef SA_LONG_NO_TB
+                continue;
+#endif
                 const int lenp = half ? lenp2 : lenp1;
                 const int lq = act ? lenq : 0;
                 const int mlen = wave_max_nonneg(lq);
@@ -233,63 +236,120 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_pair_kernel(const 
                 uint8_t* rec = (half ? out_row2 : out_row1) + (size_t)(fiq - (half ? p2 : p1) - 1) * P.stride;
                 int j = lenp, matches = 0, gaps = 0;
                 auto load_tags = [&](int sj, int r) -> uint4 {
-                    return *reinterpret_cast<const uint4*>(hd + (((size_t)sj * dir_rows + min(r, (int)dir_rows - 1)) * 64 + lane) * 4);
+                    return *reinterpret_cast<const uint4*>(hd + (((size_t)sj * dir_rows + min(max(r, 0), (int)dir_rows - 1)) * 64 + lane) * 4);
                 };
-                uint4 ring[8];
-                int ring_s[8];
+                // Requests.  The tags of a row are asked for eight rows before the walk gets there, for the strip the lane
+                // stands in at that moment (ra) and -- when the lane is within `margin` columns of that strip's left edge --
+                // for the strip to its left (rb; elsewhere rb repeats ra's address: a request that costs no traffic keeps
+                // the number of requests per row the same for every wave).  Every row issues exactly two loads and the row
+                // code below contains none, so the compiler's waits are counts ("all but the youngest fourteen"), not
+                // "everything": with a load inside the row code -- a second guess taken on the spot -- every row of every
+                // wave waited for the request it had just sent, a full trip to memory per row.
+                // rs: 2 * (strip of ra) + (1 if rb holds the strip to its left).
+                uint4 ra[8], rb[8];
+                int rs[8];
+                // columns the walk is expected to cover in eight rows, with room to spare
+                const int margin = min(64, (12 * lenp) / max(lq, 1) + 16);
+                auto request = [&](int slot, int r) {
+                    const int jc = max(j, 1) - 1;
+                    const int sn = jc >> 6;
+                    const bool wb = sn > 0 && (jc & 63) < margin;
+                    ra[slot] = load_tags(sn, r);
+                    rb[slot] = load_tags(wb ? sn - 1 : sn, r);
+                    rs[slot] = 2 * sn + (wb ? 1 : 0);
+                };
                 const int ch0 = (mlen - 1) >> 3;
-                {
-                    const int s0 = (lenp - 1) >> 6;
 #pragma unroll
-                    for (int k = 0; k < 8; k++) { ring[k] = load_tags(s0, 8 * ch0 + k); ring_s[k] = s0; }
-                }
+                for (int k = 0; k < 8; k++) request(k, 8 * ch0 + k);
                 uint2 resq = *reinterpret_cast<const uint2*>(bslot + min(8 * ch0, last_row - 7));
+                // One row with loads of its own, for every lane of the wave: the run may go through any number of strips.
+                auto row_by_loads = [&](int r, uint32_t b, int& code) {
+                    int run_total = 0, t = 1;
+                    while (j > 0) {
+                        // L = trailing zeros from column j-1 down = 2 * (LEFT moves) + (1 if an UP ends the run)
+                        const int sj = (j - 1) >> 6, jl = ((j - 1) & 63) + 1;
+                        const uint4 d = load_tags(sj, r);
+                        const uint64_t v0 = ((uint64_t)d.x << 32) | d.y;
+                        const uint64_t v1 = ((uint64_t)d.z << 32) | d.w;
+                        const bool upper = jl > 32;
+                        const int jj = upper ? jl - 32 : jl;
+                        const uint64_t x = (upper ? v1 : v0) >> ((64 - 2 * jj) & 63);
+                        const int tz0 = v0 ? __builtin_ctzll(v0) : 64;
+                        const int L = x ? __builtin_ctzll(x) : (upper ? 2 * jj + tz0 : 64);
+                        const int run = min(L >> 1, jl);
+                        j -= run;
+                        run_total += run;
+                        if (run == jl && j > 0) continue;                     // the run goes on in the strip to the left
+                        if (run < jl) t = L & 1;
+                        break;
+                    }
+                    if (t == 0) {
+                        matches += (ps[j - 1] == b) ? 1 : 0;
+                        j--;
+                    }
+                    gaps += t;
+                    code = run_total * 2 + t;
+                };
                 for (int ch = ch0; ch >= 0; --ch) {
                     uint32_t w[4] = {0, 0, 0, 0};
                     const uint2 res = resq;
-                    if (ch > 0) resq = *reinterpret_cast<const uint2*>(bslot + 8 * (ch - 1));
+                    resq = *reinterpret_cast<const uint2*>(bslot + 8 * max(ch - 1, 0));
 #pragma unroll
                     for (int k = 7; k >= 0; k--) {
                         const int r = 8 * ch + k;
-                        if (r < lq) {
-                            int run_total = 0, t = 1;
-                            bool first = true;
-                            while (j > 0) {
-                                // L = trailing zeros from column j-1 down = 2 * (LEFT moves) + (1 if an UP ends the run)
-                                const int sj = (j - 1) >> 6, jl = ((j - 1) & 63) + 1;
-                                uint4 d;
-                                if (first && ring_s[k] == sj) d = ring[k];
-                                else d = load_tags(sj, r);
-                                first = false;
-                                const uint64_t v0 = ((uint64_t)d.x << 32) | d.y;
-                                const uint64_t v1 = ((uint64_t)d.z << 32) | d.w;
-                                const bool upper = jl > 32;
-                                const int jj = upper ? jl - 32 : jl;
-                                const uint64_t x = (upper ? v1 : v0) >> ((64 - 2 * jj) & 63);
-                                const int tz0 = v0 ? __builtin_ctzll(v0) : 64;
-                                const int L = x ? __builtin_ctzll(x) : (upper ? 2 * jj + tz0 : 64);
-                                const int run = min(L >> 1, jl);
-                                j -= run;
-                                run_total += run;
-                                if (run == jl && j > 0) continue;                     // the run goes on in the strip to the left
-                                if (run < jl) t = L & 1;
-                                break;
+                        const bool on = r < lq;
+                        const uint32_t b = ((k < 4 ? res.x : res.y) >> (8 * (k & 3))) & 0xff;
+                        // the row from the tags requested eight rows ago: no load in here
+                        int run_total = 0, t = 1;
+                        bool redo = false;
+                        if (on && j > 0) {
+                            const int sj = (j - 1) >> 6, jl = ((j - 1) & 63) + 1;
+                            const int sa = rs[k] >> 1;
+                            const bool hasb = rs[k] & 1;
+                            const bool from_a = sj == sa, from_b = hasb && sj == sa - 1;
+                            redo = !(from_a || from_b);
+                            const uint4 d = from_a ? ra[k] : rb[k];
+                            const uint64_t v0 = ((uint64_t)d.x << 32) | d.y;
+                            const uint64_t v1 = ((uint64_t)d.z << 32) | d.w;
+                            const bool upper = jl > 32;
+                            const int jj = upper ? jl - 32 : jl;
+                            const uint64_t x = (upper ? v1 : v0) >> ((64 - 2 * jj) & 63);
+                            const int tz0 = v0 ? __builtin_ctzll(v0) : 64;
+                            const int L = x ? __builtin_ctzll(x) : (upper ? 2 * jj + tz0 : 64);
+                            const int run = min(L >> 1, jl);
+                            run_total = run;
+                            if (run < jl) {
+                                t = L & 1;
+                            } else if (j - run > 0) {
+                                // the run goes on in the strip to the left: rb has it, or the row is done again by loads
+                                if (from_a && hasb) {
+                                    const uint64_t e0 = ((uint64_t)rb[k].x << 32) | rb[k].y;
+                                    const uint64_t e1 = ((uint64_t)rb[k].z << 32) | rb[k].w;
+                                    const int L2 = e1 ? __builtin_ctzll(e1) : 64 + (e0 ? __builtin_ctzll(e0) : 64);
+                                    const int run2 = min(L2 >> 1, 64);
+                                    run_total = run + run2;
+                                    if (run2 < 64) t = L2 & 1;
+                                    else if (j - run_total > 0) redo = true;
+                                } else {
+                                    redo = true;
+                                }
                             }
+                        }
+                        int code = 0;
+                        if (__any(redo)) {
+                            if (on) row_by_loads(r, b, code);
+                        } else if (on) {
+                            j -= run_total;
                             if (t == 0) {
-                                const uint32_t a = ps[j - 1];
-                                const uint32_t b = ((k < 4 ? res.x : res.y) >> (8 * (k & 3))) & 0xff;
-                                matches += (a == b) ? 1 : 0;
+                                matches += (ps[j - 1] == b) ? 1 : 0;
                                 j--;
                             }
                             gaps += t;
-                            w[k >> 1] |= (uint32_t)(run_total * 2 + t) << (16 * (k & 1));
+                            code = run_total * 2 + t;
                         }
-                        if (ch > 0) {
-                            // the same row of the next piece, for the strip the walk is in now
-                            const int sn = (max(j, 1) - 1) >> 6;
-                            ring[k] = load_tags(sn, r - 8);
-                            ring_s[k] = sn;
-                        }
+                        w[k >> 1] |= (uint32_t)code << (16 * (k & 1));
+                        // the same row of the next piece, for the strip the walk is in now
+                        request(k, r - 8);
                     }
                     if (act)
                         *reinterpret_cast<uint4*>(rec + SA_LONG_HEADER_BYTES + 16 * ch) = make_uint4(w[0], w[1], w[2], w[3]);
