@@ -218,9 +218,9 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_pair_kernel(const 
 
             // --------------------------------------------------------- traceback, one half after the other
             // One row per step, bottom row first, eight rows per 16-byte piece of the record.  The tags of a row
-            // are requested eight rows ahead for the strip the walk is in at that moment (a wrong guess is loaded
-            // again when it is used); the row residues come as two dwords a piece ahead; the first sequence is
-            // read from its LDS copy.  Tag layout: column c of a strip at bits 2(15 - c%16) of dword c/16.
+            // are requested eight rows ahead (see `request` below); the row residues come as two dwords a piece ahead;
+            // the first sequence is read from its LDS copy.  Tag layout: column c of a strip at bits 2(15 - c%16) of
+            // dword c/16.
 #pragma unroll 1
             for (int half = 0; half < 2; half++) {
                 const bool act = half ? active2 : active;
