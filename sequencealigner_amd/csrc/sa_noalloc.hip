@@ -134,6 +134,12 @@ extern "C" int sa_align_adjacent_noalloc(int device, const uint8_t* d_slots, con
     int ndev = 0;
     SA_HIP_TRY(hipGetDeviceCount(&ndev));
     if (device >= ndev) return SA_ERR_ARG;
+    // the caller's current device is put back on every way out
+    struct DeviceGuard {
+        int previous = -1;
+        ~DeviceGuard() { if (previous >= 0) (void)hipSetDevice(previous); }
+    } guard;
+    SA_HIP_TRY(hipGetDevice(&guard.previous));
     SA_HIP_TRY(hipSetDevice(device));
     unsigned char* scratch = nullptr;
     int ncu = 0;
