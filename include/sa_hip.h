@@ -210,7 +210,8 @@ int sa_debug_bucket_order(sa_ctx* ctx, uint32_t* file_index, uint64_t cap, uint6
  * SA_NOALLOC_SCRATCH_BYTES in the library's device image, one copy per GPU, held until the process ends.  At
  * most SA_NOALLOC_MAX_PAIRS pairs per call (SA_ERR_NOALLOC_SIZE beyond).  The call runs on the null stream
  * and returns when the records are complete; it calls no hipMalloc / hipFree and creates no stream or event.
- * All calls on one GPU share that GPU's scratch array: calls that overlap on one GPU race. */
+ * All calls on one GPU share that GPU's scratch array: calls that overlap on one GPU race.  The call makes
+ * `device` current while it runs and puts the caller's current device back before it returns. */
 #define SA_NOALLOC_MAX_PAIRS (1u << 22)
 #define SA_NOALLOC_SCRATCH_BYTES (67u << 20)
 int sa_align_adjacent_noalloc(int device, const uint8_t* d_slots, const uint16_t* d_lens, uint64_t nseq,
