@@ -14,11 +14,30 @@
 // the register row (64 subtractions per 16 rows).  Between two moves a register holds at most
 // 16 * (17 + 64) * max S' + 15 (border growth plus growth along the strip): the host uses this
 // kernel only for tables with 1 <= S' <= 24 (BLOSUM50 with gap -4: 3 .. 23).
-// The border column travels between strips as absolute 32-bit values, one per half.
+// The border column travels between strips as the low 16 bits of its values, the two halves side by side in one
+// dword per row: a strip only uses a border value minus its base, a difference below 2^12 that the low 16 bits give
+// whatever the whole values are (they pass 2^16 for sequences of a few thousand residues).
 #include "sa_pair_common.h"
 
 #define SA_LONG_PAIR_PROF_STRIDE SA_PAIR_PROF_STRIDE(16)   /* 66 dwords; the LDS is sized for 68 (SA_LDS_PROF_BYTES) */
 #include "sa_traceback.h"
+
+// packed 16-bit arithmetic on the two halves of a dword (no carry or borrow from one half into the other)
+__device__ __forceinline__ uint32_t sa_pk_sub_u16(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_pk_sub_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t sa_pk_add_u16(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_pk_add_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t sa_pk_shl4_u16(uint32_t a) {     // each half shifted left by SA_NB_SHIFT
+    uint32_t r;
+    asm("v_pk_lshlrev_b16 %0, 4, %1 op_sel_hi:[0,1]" : "=v"(r) : "v"(a));
+    return r;
+}
 
 template <int WAVES_PER_SIMD>
 __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_pair_kernel(const SaPepParams P) {
@@ -125,12 +144,16 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_pair_kernel(const 
                 uint32_t e[8];
 #pragma unroll
                 for (int w = 0; w < 8; w++) e[w] = 0;
-                int base1 = 0, base2 = 0;
-                // border column: [half][strip parity][row / 4][lane][row % 4], absolute values
-                const int4* binA = reinterpret_cast<const int4*>(bcol + (size_t)(s & 1) * rows_cap * 64) + lane;
-                const int4* binB = reinterpret_cast<const int4*>(bcol + half_bcol + (size_t)(s & 1) * rows_cap * 64) + lane;
-                int4* boutA = reinterpret_cast<int4*>(bcol + (size_t)((s + 1) & 1) * rows_cap * 64) + lane;
-                int4* boutB = reinterpret_cast<int4*>(bcol + half_bcol + (size_t)((s + 1) & 1) * rows_cap * 64) + lane;
+                int base1 = 0, base2 = 0;     // the bases as whole numbers (for the scores) ...
+                uint32_t base12 = 0;          // ... and their low 16 bits side by side, as the border column has them
+                // Border column: [strip parity][row / 4][lane][row % 4], one dword per row: the low 16 bits of the value of
+                // the first pair's matrix in the low half, of the second pair's in the high half.  The strip to the right
+                // only ever uses a border value minus its base (the border value of at most twenty rows earlier): the
+                // difference is below 2^12 and comes out of the low 16 bits alone, whatever the whole values are.
+                // 8 bytes per row and lane of memory traffic instead of 16, one load and one store per block of four
+                // rows instead of two, and the packed forms save the shifts and masks of two separate 32-bit values.
+                const uint4* bin = reinterpret_cast<const uint4*>(bcol) + (size_t)(s & 1) * (rows_cap >> 2) * 64 + lane;
+                uint4* bout = reinterpret_cast<uint4*>(bcol) + (size_t)((s + 1) & 1) * (rows_cap >> 2) * 64 + lane;
                 uint32_t* drowA = dirs + ((size_t)s * dir_rows * 64 + lane) * 4;
                 uint32_t* drowB = drowA + half_dirs;
                 const bool first_strip = s == 0, more_strips = s + 1 < nstrips;
@@ -138,13 +161,11 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_pair_kernel(const 
                 auto residues4 = [&](int r) -> uint32_t {
                     return *reinterpret_cast<const uint32_t*>(bslot + min(r, last_row - 3));
                 };
-                auto border4 = [&](const int4* bin, int r) -> int4 {
-                    return first_strip ? make_int4(0, 0, 0, 0) : bin[(size_t)(min(r, last_row - 3) >> 2) * 64];
+                auto border4 = [&](int r) -> uint4 {
+                    return first_strip ? make_uint4(0, 0, 0, 0) : bin[(size_t)(min(r, last_row - 3) >> 2) * 64];
                 };
-                // (a, b) relative to the bases, as a left operand: 16 * (D - base) in each half
-                auto rel = [&](int a, int b) -> uint32_t {
-                    return ((uint32_t)(a - base1) << SA_NB_SHIFT) | ((uint32_t)(b - base2) << (16 + SA_NB_SHIFT));
-                };
+                // a border dword relative to the bases, as a left operand: 16 * (D - base) in each half
+                auto rel = [&](uint32_t w) -> uint32_t { return sa_pk_shl4_u16(sa_pk_sub_u16(w, base12)); };
                 // every lane stores its direction rows, also lanes whose sequence 2 has ended (never read):
                 // the stores of a block are then the same for every wave and the waits can be counted
                 auto store_dirs = [&](int r) {
@@ -158,20 +179,22 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_pair_kernel(const 
                     *reinterpret_cast<uint4*>(drowA + (size_t)r * 256) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
                     *reinterpret_cast<uint4*>(drowB + (size_t)r * 256) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
                 };
+                // the row's last cells (16 * (D - base) + tags in each half) as a border dword
+                auto border_word = [&](uint32_t y) -> uint32_t { return sa_pk_add_u16((y >> SA_NB_SHIFT) & 0x0fff0fffu, base12); };
 
                 uint32_t bres = residues4(0);
-                int4 bordA = border4(binA, 0), bordB = border4(binB, 0);
-                int prevA = 0, prevB = 0;                        // border values of the row above the block
+                uint4 bord = border4(0);
+                uint32_t prevw = 0;                              // border dword of the row above the block
                 // Every lane computes and stores every row, also lanes whose sequence 2 has ended (those rows are never
                 // read): with the row under a per-lane condition the compiler keeps a second copy of the register row
                 // for the lanes that skip it.  A lane takes its scores when its last row is done.
-#define SA_LP_ROW(RR, DA, DB, LA, LB, B)                                                                                  \
+#define SA_LP_ROW(RR, DW, LW, B)                                                                                           \
     {                                                                                                                      \
         /* the row's end tests compare this copy of gend where they stand: hoisted out of the loop each of them holds a */  \
         /* pair of scalar registers (more than there are) and comes back as two vector instructions per group            */ \
         int gr_ = gend;                                                                                                    \
         asm volatile("" : "+s"(gr_));                                                                                      \
-        fill_row_pair<SA_LP / 4, SA_LONG_PAIR_PROF_STRIDE>(R, gr_, rel(DA, DB) | SA_NB_UP_B, rel(LA, LB), prof + (B) * SA_LONG_PAIR_PROF_STRIDE, e);           \
+        fill_row_pair<SA_LP / 4, SA_LONG_PAIR_PROF_STRIDE>(R, gr_, (DW) | SA_NB_UP_B, (LW), prof + (B) * SA_LONG_PAIR_PROF_STRIDE, e);           \
     }                                                                                                                      \
     store_dirs(RR);                                                                                                        \
     if ((RR) + 1 == lenq) {                                                                                                \
@@ -180,33 +203,31 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_pair_kernel(const 
     }
                 for (int r = 0; r < maxlen; r += 4) {
                     const uint32_t nres = residues4(r + 4);
-                    const int4 nbordA = border4(binA, r + 4), nbordB = border4(binB, r + 4);
+                    const uint4 nbord = border4(r + 4);
                     const uint32_t rb0 = bres & 0xff, rb1 = (bres >> 8) & 0xff, rb2 = (bres >> 16) & 0xff, rb3 = bres >> 24;
                     if ((r & 15) == 0 && r > 0 && !first_strip) {
                         // move the bases up to the border of the row above; the register row follows
-                        const int d1 = prevA - base1, d2 = prevB - base2;
-                        const uint32_t dd = ((uint32_t)d1 << SA_NB_SHIFT) | ((uint32_t)d2 << (16 + SA_NB_SHIFT));
+                        const uint32_t d = sa_pk_sub_u16(prevw, base12);
+                        const uint32_t dd = sa_pk_shl4_u16(d);
 #pragma unroll
                         for (int c = 0; c < SA_LP; c++) R[c] -= dd;
-                        base1 += d1; base2 += d2;
+                        base1 += (int)(d & 0xffffu); base2 += (int)(d >> 16);
+                        base12 = prevw;
                     }
-                    SA_LP_ROW(r, prevA, prevB, bordA.x, bordB.x, rb0)
+                    const uint32_t l0 = rel(prevw), l1 = rel(bord.x), l2 = rel(bord.y), l3 = rel(bord.z), l4 = rel(bord.w);
+                    SA_LP_ROW(r, l0, l1, rb0)
                     const uint32_t y0 = R[SA_LP - 1];
-                    SA_LP_ROW(r + 1, bordA.x, bordB.x, bordA.y, bordB.y, rb1)
+                    SA_LP_ROW(r + 1, l1, l2, rb1)
                     const uint32_t y1 = R[SA_LP - 1];
-                    SA_LP_ROW(r + 2, bordA.y, bordB.y, bordA.z, bordB.z, rb2)
+                    SA_LP_ROW(r + 2, l2, l3, rb2)
                     const uint32_t y2 = R[SA_LP - 1];
-                    SA_LP_ROW(r + 3, bordA.z, bordB.z, bordA.w, bordB.w, rb3)
+                    SA_LP_ROW(r + 3, l3, l4, rb3)
                     const uint32_t y3 = R[SA_LP - 1];
-                    if (more_strips) {
-                        boutA[(size_t)(r >> 2) * 64] = make_int4((int)((y0 & 0xffffu) >> SA_NB_SHIFT) + base1, (int)((y1 & 0xffffu) >> SA_NB_SHIFT) + base1,
-                                                                 (int)((y2 & 0xffffu) >> SA_NB_SHIFT) + base1, (int)((y3 & 0xffffu) >> SA_NB_SHIFT) + base1);
-                        boutB[(size_t)(r >> 2) * 64] = make_int4((int)(y0 >> (16 + SA_NB_SHIFT)) + base2, (int)(y1 >> (16 + SA_NB_SHIFT)) + base2,
-                                                                 (int)(y2 >> (16 + SA_NB_SHIFT)) + base2, (int)(y3 >> (16 + SA_NB_SHIFT)) + base2);
-                    }
-                    prevA = bordA.w; prevB = bordB.w;
+                    if (more_strips)
+                        bout[(size_t)(r >> 2) * 64] = make_uint4(border_word(y0), border_word(y1), border_word(y2), border_word(y3));
+                    prevw = bord.w;
                     bres = nres;
-                    bordA = nbordA; bordB = nbordB;
+                    bord = nbord;
                 }
 #undef SA_LP_ROW
                 // the scores sit in the strips that hold each half's last column

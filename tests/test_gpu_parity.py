@@ -168,6 +168,28 @@ def test_longest_supported_sequences():
         _check_pairs(al, rec, [(k, k + 1) for k in range(len(seqs) - 1)])
 
 
+def test_long_sequences_whose_matrix_values_pass_16_bits():
+    """Near-identical sequences of 4096 residues: D reaches 4096 * 23 = 94 208 with the default table, so the strip
+    border columns, which the packed long kernel hands from strip to strip as the low 16 bits of the values, wrap
+    round; scores, paths and statistics must still be the checker's (and the 32-bit kernel's records)."""
+    rng = random.Random(23)
+    w = "W" * 4096
+    noisy = list(w)
+    for _ in range(40):
+        noisy[rng.randrange(4096)] = rng.choice(ALPHABET)
+    seqs = [w, "".join(noisy), "W" * 4000 + "C" * 96, "W" * 3500, "Y" * 2000 + "W" * 2096, w[:4095], "F" * 300 + w[:3700]]
+    al = sa.Aligner(max_seq_len=4096)
+    al.set_cooperative(-1)
+    al.upload(seqs)
+    rec = al.align(sa.TRIANGULAR)
+    assert al.last_kernel().startswith("sa_long_pair_kernel")
+    _check_pairs(al, rec, _tri_pairs(len(seqs), 0, len(seqs) - 1))
+    al.set_pairing(False)
+    rec32 = al.align(sa.TRIANGULAR)
+    assert al.last_kernel().startswith("sa_long_kernel")
+    assert np.array_equal(rec, rec32)
+
+
 def test_row_ranges_and_shards_concatenate_to_the_whole():
     seqs, _ = synth.generate(1500, 6, 50, seed=51)
     al = sa.Aligner()
