@@ -68,11 +68,19 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
             const int a1 = P.codes_fo[(size_t)p1 * SA_LP + lane];
             const int a2 = has2 ? (int)P.codes_fo[(size_t)p2 * SA_LP + lane] : SA_PAD_CODE;
             __syncthreads();   // previous item's readers are done with prof/pcol
+            // all forty table values are requested before the first is used: one trip to memory per item, not twenty
+            // (the loads of a row's two values used to sit between the previous row's LDS write and its own)
+            int t1[20], t2[20];
+#pragma unroll
+            for (int b = 0; b < 20; b++) {
+                t1[b] = P.sprime[a1 * SA_SPRIME_STRIDE + b];
+                t2[b] = P.sprime[a2 * SA_SPRIME_STRIDE + b];
+            }
 #pragma unroll
             for (int b = 0; b < 20; b++) {
                 // padding scores 1 instead of 0 (an odd column's table entry must stay positive); padded cells
                 // lie to the right of and below every cell that is read
-                const int s1 = max(P.sprime[a1 * SA_SPRIME_STRIDE + b], 1), s2 = max(P.sprime[a2 * SA_SPRIME_STRIDE + b], 1);
+                const int s1 = max(t1[b], 1), s2 = max(t2[b], 1);
                 if (lane < PS) prof[b * PS + SA_NB_PROF_INDEX(lane, PS)] = (lane & 1) ? SA_NB_TABLE_B(s1) | (SA_NB_TABLE_B(s2) << 16)
                                                              : SA_NB_TABLE_A(s1) | (SA_NB_TABLE_A(s2) << 16);
             }
