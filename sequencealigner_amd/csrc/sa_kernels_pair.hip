@@ -104,18 +104,35 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
             const bool active = vl < nvalid;
             if (!__any(active)) continue;
             uint32_t sidx = 0, cum = item.c0;
-            const uint32_t* cur_row = P.cursor + (size_t)p1 * P.nb;
+            // read through the constant address space: the tables do not change during the launch, the addresses are
+            // wave-uniform, and loads of this kind go through the scalar cache instead of the vector memory pipeline
+            typedef const __attribute__((address_space(4))) uint32_t* sa_const_u32;
+            const sa_const_u32 cur_row = (sa_const_u32)(P.cursor + (size_t)p1 * P.nb);
+            const sa_const_u32 bucket_base = (sa_const_u32)P.bucket_base;
             for (uint32_t b = item.b0; b < P.nb; b++) {
-                const uint32_t first = P.bucket_base[b] + cur_row[b];
-                const uint32_t cnt = P.bucket_base[b + 1] - first;
+                const uint32_t first = bucket_base[b] + cur_row[b];
+                const uint32_t cnt = bucket_base[b + 1] - first;
                 if (vl >= cum && vl < cum + cnt) sidx = first + (vl - cum);
                 cum += cnt;
                 if (cum > vbase + 63) break;
             }
             const uint32_t fiq = P.fi_sorted[sidx];
             const int lenq = active ? (int)P.len_sorted[sidx] : 0;
+            // the first 16-byte piece of the lane's second sequence is always needed: it is requested with the two loads
+            // above, the further pieces (as far as the wave's longest second sequence reaches) in one batch below -- two
+            // trips to memory per task where there were up to five, each piece's load waited for before the next was sent
+            const uint4* const qsrc = reinterpret_cast<const uint4*>(P.codes_s) + sidx;
+            const uint4 q0 = qsrc[0];
             const bool active2 = active && has2 && fiq > p2;
             const int maxlen = wave_max_nonneg(lenq);
+            // only the pieces that hold residues of the wave's longest second sequence (plus the one the row loop's
+            // look-ahead may touch); the pieces are stored piece-major, so what is not requested is not fetched either
+            // (64-byte slots cost 55 GB of reads per launch of 50 000 peptides)
+            const int nq = min(4, (maxlen >> 4) + 1);
+            uint4 q1 = q0, q2 = q0, q3 = q0;
+            if (nq > 1) q1 = qsrc[(size_t)P.npad];
+            if (nq > 2) q2 = qsrc[(size_t)2 * P.npad];
+            if (nq > 3) q3 = qsrc[(size_t)3 * P.npad];
             SA_PHASE(2);
 
             // -------------------------------------------------------------- fill
@@ -133,20 +150,11 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
             // before: requests complete in order.)
             uint8_t* const qres = reinterpret_cast<uint8_t*>(stage + lane * SD + 2);
             {
-                const uint4* src = reinterpret_cast<const uint4*>(P.codes_s) + sidx;
                 uint2* dst = reinterpret_cast<uint2*>(qres);
-                // only the 16-byte pieces that hold residues of the wave's longest second sequence (plus the one
-                // the row loop's look-ahead may touch); the pieces are stored piece-major, so what is not requested
-                // is not fetched either (64-byte slots cost 55 GB of reads per launch of 50 000 peptides)
-                const int nq = min(4, (maxlen >> 4) + 1);
-#pragma unroll
-                for (int q4 = 0; q4 < 4; q4++) {
-                    if (q4 < nq) {
-                        const uint4 v = src[(size_t)q4 * P.npad];
-                        dst[2 * q4] = make_uint2(v.x, v.y);
-                        dst[2 * q4 + 1] = make_uint2(v.z, v.w);
-                    }
-                }
+                dst[0] = make_uint2(q0.x, q0.y); dst[1] = make_uint2(q0.z, q0.w);
+                if (nq > 1) { dst[2] = make_uint2(q1.x, q1.y); dst[3] = make_uint2(q1.z, q1.w); }
+                if (nq > 2) { dst[4] = make_uint2(q2.x, q2.y); dst[5] = make_uint2(q2.z, q2.w); }
+                if (nq > 3) { dst[6] = make_uint2(q3.x, q3.y); dst[7] = make_uint2(q3.z, q3.w); }
             }
             // Direction rows, one pair at a time: 16-bit pieces of eight columns, n16 per row and lane; the rows of the
             // low halves first, then those of the high halves (layout and register form: traceback_pk).
