@@ -124,10 +124,14 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_kernel(const Sa
                 active = vl < nvalid;
                 if (!__any(active)) continue;
                 uint32_t sidx = 0, cum = item.c0;
-                const uint32_t* cur_row = P.cursor + (size_t)item.p * P.nb;
+                // read through the constant address space: the tables do not change during the launch, the addresses
+                // are wave-uniform, and loads of this kind are scalar loads instead of trips through the vector memory path
+                typedef const __attribute__((address_space(4))) uint32_t* sa_const_u32;
+                const sa_const_u32 cur_row = (sa_const_u32)(P.cursor + (size_t)item.p * P.nb);
+                const sa_const_u32 bucket_base = (sa_const_u32)P.bucket_base;
                 for (uint32_t b = item.b0; b < P.nb; b++) {
-                    const uint32_t first = P.bucket_base[b] + cur_row[b];
-                    const uint32_t cnt = P.bucket_base[b + 1] - first;
+                    const uint32_t first = bucket_base[b] + cur_row[b];
+                    const uint32_t cnt = bucket_base[b + 1] - first;
                     if (vl >= cum && vl < cum + cnt) sidx = first + (vl - cum);
                     cum += cnt;
                     if (cum > vbase + 63) break;
