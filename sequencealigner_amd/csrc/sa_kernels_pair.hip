@@ -326,14 +326,22 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
                     const uint32_t relact = act ? rel : 0xffffffffu;
                     const uint32_t* const src = stage + (lane >> 2) * SD + (lane & 3) * 4;
                     uint8_t* const dst = out_row + (lane & 3) * 16;
+                    // the four exchanges first, then the eight staging reads, then the stores: two trips to the LDS
+                    // for the task's records of this half instead of eight
+                    uint32_t rrel[4];
+#pragma unroll
+                    for (int round = 0; round < 4; round++) rrel[round] = __shfl(relact, (lane >> 2) + 16 * round, 64);
+                    uint2 va[4], vb[4];
 #pragma unroll
                     for (int round = 0; round < 4; round++) {
-                        const uint32_t rrel = __shfl(relact, (lane >> 2) + 16 * round, 64);
-                        if (rrel != 0xffffffffu) {
-                            const uint2 va = *reinterpret_cast<const uint2*>(src + round * 16 * SD);
-                            const uint2 vb = *reinterpret_cast<const uint2*>(src + round * 16 * SD + 2);
-                            const sa_u32x4 v = {va.x, va.y, vb.x, vb.y};
-                            __builtin_nontemporal_store(v, reinterpret_cast<sa_u32x4*>(dst + (uint64_t)rrel * 64));
+                        va[round] = *reinterpret_cast<const uint2*>(src + round * 16 * SD);
+                        vb[round] = *reinterpret_cast<const uint2*>(src + round * 16 * SD + 2);
+                    }
+#pragma unroll
+                    for (int round = 0; round < 4; round++) {
+                        if (rrel[round] != 0xffffffffu) {
+                            const sa_u32x4 v = {va[round].x, va[round].y, vb[round].x, vb[round].y};
+                            __builtin_nontemporal_store(v, reinterpret_cast<sa_u32x4*>(dst + (uint64_t)rrel[round] * 64));
                         }
                     }
                 } else {
