@@ -61,12 +61,35 @@ WORKLOADS = {
 }
 
 
+def visible_gpus():
+    """GPUs of this machine counted from the kernel driver's topology files (nodes with shader engines), without
+    loading torch or any HIP library: the process that starts the ranks must not have initialised a GPU.
+    None when the topology cannot be read (the ranks then find out for themselves)."""
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        nodes = os.listdir(base)
+    except OSError:
+        return None
+    count = 0
+    for node in nodes:
+        try:
+            with open(os.path.join(base, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) > 0:
+            count += 1
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        if os.environ.get(var, "").strip():
+            count = min(count, len([d for d in os.environ[var].split(",") if d.strip()]))
+    return count
+
+
 def spawn_ranks(args):
-    """--gpus N outside a torchrun environment: start the N ranks as a fresh child job.  Nothing in this
-    process has touched a GPU yet (counting devices does not initialise one)."""
-    import torch
-    have = torch.cuda.device_count()
-    if have < args.gpus:
+    """--gpus N outside a torchrun environment: start the N ranks as a fresh child job.  This process never
+    touches a GPU: it imports neither torch nor the library, and counts devices from sysfs."""
+    have = visible_gpus()
+    if have is not None and have < args.gpus and "SA_BENCH_DEVICE" not in os.environ:
         print(f"bench.py: --gpus {args.gpus} asked for, {have} visible", file=sys.stderr)
         return 2
     port = 29500 + os.getpid() % 2000

@@ -173,7 +173,8 @@ int sa_set_pairing(sa_ctx* ctx, int enable);
  * every pair a whole wave (the 64 lanes sweep anti-diagonals of one matrix and hand their operands to the neighbour
  * lane) instead of a lane: a few hundred protein pairs then use a few hundred waves, not a handful.  The reference
  * handles one pair per call of align_sequences (include/seqalign.h:13-113) whatever the count.  mode 0 (default)
- * chooses by the pair count of the submission, 1 = always for long sequences, -1 = never.  Same records either way. */
+ * chooses by the pair count of the submission, 1 = for every submission of long sequences of up to 4096 pairs per CU
+ * (beyond that the per-pair work list would not be worth its memory), -1 = never.  Same records either way. */
 int sa_set_cooperative(sa_ctx* ctx, int mode);
 
 /* name of the fill + traceback kernel the context's most recent launch ran ("" before the first): the library picks
@@ -197,8 +198,8 @@ int sa_debug_work_items(sa_ctx* ctx, int schedule, uint64_t row_begin, uint64_t 
 int sa_debug_bucket_order(sa_ctx* ctx, uint32_t* file_index, uint64_t cap, uint64_t* count);
 
 /* ---- one entry point that allocates nothing.  No counterpart in the reference: it is for callers that
- * cannot allocate device memory (code under HIP graph capture rules, tight serving loops, harnesses that
- * forbid hipMalloc).  It is the ADJACENT peptide path of sa_submit / sa_next with every buffer passed in:
+ * cannot allocate device memory (tight serving loops, harnesses that forbid hipMalloc; not stream
+ * capture: the call synchronises with the host).  It is the ADJACENT peptide path of sa_submit / sa_next with every buffer passed in:
  *   d_slots    device memory, nseq slots of 64 bytes: residue codes 0..19 of sequence s, then padding (any
  *              value; 20 is what sa_upload writes)
  *   d_lens     device memory, nseq lengths (uint16), each 1 .. 64
@@ -213,7 +214,7 @@ int sa_debug_bucket_order(sa_ctx* ctx, uint32_t* file_index, uint64_t cap, uint6
  * All calls on one GPU share that GPU's scratch array: calls that overlap on one GPU race.  The call makes
  * `device` current while it runs and puts the caller's current device back before it returns. */
 #define SA_NOALLOC_MAX_PAIRS (1u << 22)
-#define SA_NOALLOC_SCRATCH_BYTES (67u << 20)
+#define SA_NOALLOC_SCRATCH_BYTES (131u << 20)
 int sa_align_adjacent_noalloc(int device, const uint8_t* d_slots, const uint16_t* d_lens, uint64_t nseq,
                               const int32_t* S, int32_t gap, uint8_t* d_records, uint32_t stride);
 

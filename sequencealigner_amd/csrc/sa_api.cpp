@@ -372,9 +372,13 @@ uint32_t long_dir_rows(const sa_ctx* c) { return (c->max_seq + 7u) & ~7u; }
 // (tools/coop_crossover.py): 16 471 pairs 3.4 ms against 21.4 ms, 65 341 pairs 12.6 against 22.1, 130 816 pairs 24.3
 // against 22.6 -- the pair-per-lane kernels take about 22 ms whatever the count until the chip is full, this one
 // 0.19 us per pair.  Up to 384 pairs per CU go here.
+// Forced (sa_set_cooperative(ctx, 1)) it still takes at most 4096 pairs per CU: its work list is one 32-byte item
+// per pair, built and sorted on the host, and a whole TRIANGULAR schedule of 10 000 proteins would be 1.6 GB of it;
+// larger submissions run on the pair-per-lane kernels whatever the mode.
 bool use_coop(const sa_ctx* c, uint64_t npairs) {
     if (c->lslot <= SA_LP || c->coop_mode < 0 || npairs == 0) return false;
-    return c->coop_mode > 0 || npairs <= 384ull * (uint64_t)c->ncu;
+    if (c->coop_mode > 0) return npairs <= 4096ull * (uint64_t)c->ncu;
+    return npairs <= 384ull * (uint64_t)c->ncu;
 }
 // its scratch per workgroup, KiB: direction blocks (strips x 16-step blocks x 256 B), two border columns, row notes
 uint32_t coop_kib_per_wg(const sa_ctx* c) {
@@ -508,7 +512,17 @@ int launch_status(const Work& w) {
     return *(const uint32_t*)w.status_pin.p ? SA_ERR_KERNEL : SA_OK;
 }
 
+int prepare_work_impl(sa_ctx* c, Work& w, int schedule, uint64_t r0, uint64_t r1, bool need_host);
+// no exception leaves the C ABI: a work list that does not fit the host's memory is SA_ERR_NOMEM
 int prepare_work(sa_ctx* c, Work& w, int schedule, uint64_t r0, uint64_t r1, bool need_host) {
+    try {
+        return prepare_work_impl(c, w, schedule, r0, r1, need_host);
+    } catch (const std::bad_alloc&) {
+        return SA_ERR_NOMEM;
+    }
+}
+
+int prepare_work_impl(sa_ctx* c, Work& w, int schedule, uint64_t r0, uint64_t r1, bool need_host) {
     std::vector<SaItem> items;
     bool paired = true;
     int rc = SA_OK;

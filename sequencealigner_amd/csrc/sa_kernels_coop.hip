@@ -49,7 +49,7 @@ __device__ __forceinline__ int sa_wave_shr1(int old_for_lane0, int v) {
 __device__ __forceinline__ uint32_t sa_writelane(int value, int lane_index, uint32_t dst) {
     value = __builtin_amdgcn_readfirstlane(value);
     lane_index = __builtin_amdgcn_readfirstlane(lane_index);
-    asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(dst) : "s"(value), "s"(lane_index));  /* M0 is otherwise unused in this kernel */
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(dst) : "s"(value), "s"(lane_index) : "m0");
     return dst;
 }
 

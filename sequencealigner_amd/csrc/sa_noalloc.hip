@@ -1,5 +1,7 @@
 // sa_noalloc.hip -- sa_align_adjacent_noalloc: the ADJACENT peptide path for callers that cannot
 // allocate device memory (code that must not call hipMalloc: serving loops, harnesses that forbid it).
+// It synchronises with the host (status words come back before the main launch), so it is not for use
+// inside a stream capture.
 //
 // The caller passes the sequences and the record buffer as device pointers.  Everything else the
 // kernels need beyond inputs and outputs -- the work-queue head, the work list, the shifted
@@ -36,7 +38,7 @@ constexpr size_t kItemsOff = 4096;
 constexpr size_t kMaxItems = (SA_NOALLOC_MAX_PAIRS + 63) / 64;
 constexpr size_t kItemsBytes = kMaxItems * sizeof(SaItem);
 constexpr size_t kSpillOff = kItemsOff + kItemsBytes;
-constexpr unsigned kMaxGrid = 1024;                                    // workgroups of one launch
+constexpr unsigned kMaxGrid = 2048;                                    // workgroups of one launch: eight per CU of a 256-CU chip
 constexpr unsigned kSpillRows = SA_LP;                                 // direction rows per workgroup, 1 KiB each
 constexpr size_t kSpillBytes = (size_t)kMaxGrid * kSpillRows * 1024;
 constexpr size_t kScratchBytes = kSpillOff + kSpillBytes;
@@ -189,8 +191,9 @@ extern "C" int sa_align_adjacent_noalloc(int device, const uint8_t* d_slots, con
     P.nseq = (uint32_t)nseq;
     P.gap = gap;
     P.lslot = SA_LP;
-    // two waves per SIMD of the ADJACENT kernel reside: eight workgroups per CU; never more than the scratch holds
-    const unsigned grid = std::min<unsigned>(kMaxGrid, std::min<unsigned>((unsigned)std::max(1, ncu) * 4u, nitems));
+    // two waves per SIMD of the ADJACENT kernel reside: eight workgroups per CU, as sa_submit launches it; never more
+    // than the scratch array has direction rows for
+    const unsigned grid = std::min<unsigned>(kMaxGrid, std::min<unsigned>((unsigned)std::max(1, ncu) * 8u, nitems));
     sa_launch_peptide(1 /* ADJACENT */, 2, &P, grid, SA_LDS_FIXED_BYTES, stream);
     SA_HIP_TRY(hipGetLastError());
     SA_HIP_TRY(hipStreamSynchronize(stream));

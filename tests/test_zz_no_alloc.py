@@ -30,15 +30,24 @@ def _device_inputs(seqs):
     return torch.from_numpy(slots).cuda(), torch.from_numpy(lens.view(np.int16)).cuda()
 
 
-def _noalloc(seqs, stride, matrix=None, gap=-4):
+def _noalloc(seqs, stride, matrix=None, gap=-4, device=0, check_nothing_allocated=False):
     lib = sa.load_library()
-    d_slots, d_lens = _device_inputs(seqs)
-    out = torch.full(((len(seqs) - 1) * stride,), 0xEE, dtype=torch.uint8, device="cuda")
-    torch.cuda.synchronize()
+    with torch.cuda.device(device):
+        d_slots, d_lens = _device_inputs(seqs)
+        out = torch.full(((len(seqs) - 1) * stride,), 0xEE, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
     mat = None
     if matrix is not None:
         mat = (C.c_int32 * 400)(*matrix)
-    rc = lib.sa_align_adjacent_noalloc(0, d_slots.data_ptr(), d_lens.data_ptr(), len(seqs), mat, gap, out.data_ptr(), stride)
+    current = torch.cuda.current_device()
+    free_before = torch.cuda.mem_get_info(device)[0]
+    rc = lib.sa_align_adjacent_noalloc(device, d_slots.data_ptr(), d_lens.data_ptr(), len(seqs), mat, gap, out.data_ptr(), stride)
+    assert torch.cuda.current_device() == current          # the caller's device is put back
+    hip_device = C.c_int(-1)
+    assert C.CDLL("libamdhip64.so").hipGetDevice(C.byref(hip_device)) == 0 and hip_device.value == current
+    if check_nothing_allocated:
+        # what the driver reports as free on the card is what it was before the call: nothing allocated, nothing freed
+        assert torch.cuda.mem_get_info(device)[0] == free_before
     return rc, out.cpu().numpy().reshape(len(seqs) - 1, stride)
 
 
@@ -65,12 +74,16 @@ def test_noalloc_entry_point_equals_submit_on_two_calls_in_a_row():
     small = ["".join(rng.choice(ALPHABET) for _ in range(rng.randint(1, 40))) for _ in range(777)]
     want_small, stride_small = _reference_records(small, matrix=matrix, gap=-3)
     assert stride_small < stride_big
-    rc, got_small = _noalloc(small, stride_small, matrix=matrix, gap=-3)
+    rc, got_small = _noalloc(small, stride_small, matrix=matrix, gap=-3, check_nothing_allocated=True)
     assert rc == 0, sa.load_library().sa_strerror(rc)
     assert np.array_equal(got_small, want_small)
     # and the first input once more: same bytes as before
-    rc, again = _noalloc(big, stride_big)
+    rc, again = _noalloc(big, stride_big, check_nothing_allocated=True)
     assert rc == 0 and np.array_equal(again, want_big)
+    if torch.cuda.device_count() > 1:
+        # another GPU has its own copy of the scratch array at its own address; device 0 stays the current one
+        rc, other = _noalloc(small, stride_small, matrix=matrix, gap=-3, device=1)
+        assert rc == 0 and np.array_equal(other, want_small)
 
 
 def test_noalloc_entry_point_rejects_what_it_cannot_serve():
