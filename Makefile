@@ -22,8 +22,18 @@ sequencealigner_amd/sa_dataset: $(CSRC)/sa_dataset.c
 	gcc -O2 -Wall -Wextra -o $@ $(CSRC)/sa_dataset.c
 $(MAIN): $(CSRC)/sa_main.cpp $(LIB)
 	$(HIPCC) -O2 -std=c++17 -Wall -o $@ $(CSRC)/sa_main.cpp -Lsequencealigner_amd -lsa_hip -Wl,-rpath,'$$ORIGIN'
-$(LIB): $(CSRC)/sa_kernel_common.h $(CSRC)/sa_traceback.h $(CSRC)/sa_pair_common.h $(CSRC)/sa_parallel.h $(CSRC)/sa_kernels.hip $(CSRC)/sa_kernels_pair.hip $(CSRC)/sa_kernels_long.hip $(CSRC)/sa_kernels_long_pair.hip $(CSRC)/sa_kernels_coop.hip $(CSRC)/sa_format.hip $(CSRC)/sa_noalloc.hip $(CSRC)/sa_api.cpp $(CSRC)/sa_host.cpp $(CSRC)/sa_device.h include/sa_hip.h include/sa_host.h
-	$(HIPCC) $(HIPFLAGS) -shared -pthread -o $@ $(CSRC)/sa_kernels.hip $(CSRC)/sa_kernels_pair.hip $(CSRC)/sa_kernels_long.hip $(CSRC)/sa_kernels_long_pair.hip $(CSRC)/sa_kernels_coop.hip $(CSRC)/sa_format.hip $(CSRC)/sa_noalloc.hip $(CSRC)/sa_api.cpp $(CSRC)/sa_host.cpp
+# one object per source, so that a change to one kernel recompiles one file
+OBJDIR  := build/lib
+LIBSRC  := sa_kernels.hip sa_kernels_pair.hip sa_kernels_long.hip sa_kernels_long_pair.hip sa_kernels_long_ckpt.hip \
+           sa_kernels_coop.hip sa_format.hip sa_noalloc.hip sa_compact.hip sa_api.cpp sa_host.cpp
+LIBOBJ  := $(addprefix $(OBJDIR)/,$(addsuffix .o,$(LIBSRC)))
+LIBHDR  := $(CSRC)/sa_kernel_common.h $(CSRC)/sa_traceback.h $(CSRC)/sa_pair_common.h $(CSRC)/sa_parallel.h $(CSRC)/sa_device.h \
+           include/sa_hip.h include/sa_host.h
+$(OBJDIR)/%.o: $(CSRC)/% $(LIBHDR)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+$(LIB): $(LIBOBJ)
+	$(HIPCC) --offload-arch=$(ARCH) -fPIC -shared -pthread -o $@ $(LIBOBJ)
 
 oracle:
 	$(MAKE) -C oracle all

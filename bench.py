@@ -64,12 +64,12 @@ WORKLOADS = {
 def visible_gpus():
     """GPUs of this machine counted from the kernel driver's topology files (nodes with shader engines), without
     loading torch or any HIP library: the process that starts the ranks must not have initialised a GPU.
-    None when the topology cannot be read (the ranks then find out for themselves)."""
+    Without the driver's topology directory there is no GPU this library could use: 0."""
     base = "/sys/class/kfd/kfd/topology/nodes"
     try:
         nodes = os.listdir(base)
     except OSError:
-        return None
+        return 0
     count = 0
     for node in nodes:
         try:
@@ -89,7 +89,7 @@ def spawn_ranks(args):
     """--gpus N outside a torchrun environment: start the N ranks as a fresh child job.  This process never
     touches a GPU: it imports neither torch nor the library, and counts devices from sysfs."""
     have = visible_gpus()
-    if have is not None and have < args.gpus and "SA_BENCH_DEVICE" not in os.environ:
+    if have < args.gpus and "SA_BENCH_DEVICE" not in os.environ:
         print(f"bench.py: --gpus {args.gpus} asked for, {have} visible", file=sys.stderr)
         return 2
     port = 29500 + os.getpid() % 2000

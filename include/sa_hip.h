@@ -169,6 +169,13 @@ int sa_set_bucket_width(sa_ctx* ctx, uint32_t width);
  * and longest sequence * max(S - 2*gap) <= 1983 when no sequence exceeds 64 residues; 1 .. 24 otherwise).  enable = 0 forces one first
  * sequence per wave, 32-bit cells (same results; for comparisons and tests).  Default: enabled. */
 int sa_set_pairing(sa_ctx* ctx, int enable);
+/* Sequences longer than 64 residues on the packed TRIANGULAR kernel: how the traceback gets its directions.  The
+ * reference keeps the whole score matrix of a pair and walks it (include/seqalign.h:18,63-88).  rows = 64 (default) or
+ * 32: the fill keeps values only and leaves a checkpoint (one matrix row per strip) every `rows` rows plus the last
+ * column of every strip; the traceback fills again, with direction tags, only the tiles its path goes through.
+ * rows = 0: the fill writes two direction bits for every cell and the traceback reads them back (the earlier kernel;
+ * four times the scratch memory).  Same records either way. */
+int sa_set_long_checkpoint_rows(sa_ctx* ctx, uint32_t rows);
 /* Sequences longer than 64 residues, few pairs: a submission of at most 384 pairs per CU runs on a kernel that gives
  * every pair a whole wave (the 64 lanes sweep anti-diagonals of one matrix and hand their operands to the neighbour
  * lane) instead of a lane: a few hundred protein pairs then use a few hundred waves, not a handful.  The reference

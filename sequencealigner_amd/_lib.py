@@ -135,6 +135,7 @@ SIGNATURES = {
     "sa_last_kernel": (C.c_char_p, [C.c_void_p]),
     "sa_set_pairing": (C.c_int, [C.c_void_p, C.c_int]),
     "sa_set_cooperative": (C.c_int, [C.c_void_p, C.c_int]),
+    "sa_set_long_checkpoint_rows": (C.c_int, [C.c_void_p, C.c_uint32]),
     "sa_set_text_layout": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sa_upload_passthrough": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.c_uint64]),
     "sa_submit_text": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64]),
@@ -310,6 +311,10 @@ class Aligner:
     def set_cooperative(self, mode):
         """Wave-per-pair kernel for long sequences: 0 = by pair count (default), 1 = always, -1 = never."""
         _check(self._lib.sa_set_cooperative(self._ctx, mode))
+
+    def set_long_checkpoint_rows(self, rows):
+        """Packed long-sequence kernel: 64 (default) or 32 rows between checkpoints, 0 = whole direction matrix."""
+        _check(self._lib.sa_set_long_checkpoint_rows(self._ctx, rows))
 
     def set_bucket_width(self, width):
         _check(self._lib.sa_set_bucket_width(self._ctx, width))

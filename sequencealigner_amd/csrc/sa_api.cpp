@@ -27,6 +27,7 @@ extern "C" void sa_launch_peptide_pair(int ng, const SaPepParams* p, unsigned gr
 extern "C" size_t sa_format_scan_bytes(uint64_t n);
 extern "C" hipError_t sa_launch_format(const SaFormatParams* F, void* scan_tmp, size_t scan_bytes, hipStream_t stream);
 extern "C" void sa_launch_long_pair(const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream);
+extern "C" void sa_launch_long_ckpt(int ck_rows, const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream);
 extern "C" void sa_launch_coop(const SaPepParams* p, unsigned grid, hipStream_t stream);
 extern "C" void sa_launch_long(int mode, const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream);
 
@@ -126,6 +127,7 @@ struct sa_ctx {
     int64_t sprime_min = 0, sprime_max = 0;   // range of S' = S - 2*gap over the table: decides whether packed cells fit
     uint32_t bucket_width = 1;
     int coop_mode = 0;                 // wave-per-pair kernel for long sequences: 0 = when a submission has few pairs, 1 always, -1 never
+    uint32_t ckpt_rows = 64;           // paired long-sequence kernel: rows between checkpoints (32 or 64); 0 = the kernel that stores a whole direction matrix
     uint32_t bucket_width_forced = 0;  // sa_set_bucket_width: 0 = from the number of sequences per length
     // sequences (host mirror)
     uint64_t nseq = 0;
@@ -387,10 +389,20 @@ uint32_t coop_kib_per_wg(const sa_ctx* c) {
     return (uint32_t)((bytes + 1023) / 1024);
 }
 
+// rows of the checkpointing kernel's border columns and checkpoints: the longest uploaded sequence, rounded up to 64
+uint32_t long_ckpt_rows_cap(const sa_ctx* c) { return (c->max_seq + 63u) & ~63u; }
+
 // global scratch of one workgroup: direction rows (and, for long sequences, the strip border columns)
 size_t spill_bytes_per_wg(const sa_ctx* c) {
     if (!is_long(c)) return (size_t)2 * SA_LP * 1024;      // two sets of direction rows for the paired kernel
-    return (size_t)2 * (c->lslot / 64) * long_dir_rows(c) * 1024;   // strips x rows x 1 KiB, for each half of the paired kernel
+    const size_t strips = c->lslot / 64;
+    const size_t one_matrix = strips * long_dir_rows(c) * 1024;      // strips x rows x 1 KiB: the 32-bit kernel's direction rows
+    if (c->ckpt_rows == 0 || !uses_pairs(c)) return 2 * one_matrix; // one per half of the paired kernel
+    // checkpointing kernel: tile tags (2 x CK KiB), border columns of every strip (256 B per row), every CK-th row of
+    // every strip (16 KiB each); row ranges that run unpaired still need the 32-bit kernel's direction rows
+    const size_t rows = long_ckpt_rows_cap(c);
+    const size_t ck = (size_t)2 * c->ckpt_rows * 1024 + strips * rows * 256 + (rows / c->ckpt_rows) * strips * 16384;
+    return std::max(ck, one_matrix);
 }
 
 // 4-column register groups of the paired peptide kernel's row: 13 (52 columns) when no sequence is longer
@@ -404,6 +416,7 @@ uint32_t grid_for(const sa_ctx* c) {
         const uint64_t budget = c->spill_budget;
         uint64_t per_cu = 8;
         if (uses_pairs(c)) per_cu = std::min<uint64_t>(16, (160u * 1024u) / (SA_LDS_PROF_BYTES + 64 + 2 * c->lslot));
+        if (c->wg_per_cu) per_cu = std::min<uint64_t>(per_cu, c->wg_per_cu);      // sa_set_tuning: fewer, for measurements
         uint64_t g = std::min<uint64_t>((uint64_t)c->ncu * per_cu, budget / spill_bytes_per_wg(c));
         return (uint32_t)std::max<uint64_t>(1, g);
     }
@@ -417,11 +430,12 @@ uint32_t grid_for(const sa_ctx* c) {
 }
 
 int ensure_spill(sa_ctx* c, uint32_t grid) {
-    if (grid <= c->spill_grid) return SA_OK;
+    // sized in bytes for this launch's grid and the current kernel choice (pairing and the checkpoint setting change
+    // what a workgroup needs); the buffers only ever grow
     int rc = c->d_spill.reserve((size_t)grid * spill_bytes_per_wg(c));
     if (rc) return rc;
     if (is_long(c) && (rc = c->d_bcol.reserve((size_t)grid * 4 * c->lslot * 256))) return rc;
-    c->spill_grid = grid;
+    c->spill_grid = std::max(c->spill_grid, grid);
     return SA_OK;
 }
 
@@ -434,6 +448,7 @@ int launch_work(sa_ctx* c, Work& w, bool timed) {
         // 125 GiB; with less the launch runs fewer waves per SIMD.  16 GiB stay free for the second slot's records.
         size_t free_b = 0, total_b = 0;
         SA_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        free_b += c->d_spill.cap + c->d_bcol.cap;      // what an earlier layout of the scratch areas holds is reused
         // Three quarters of what is free at most (other contexts may share the card) and never the last 16 GiB.
         const uint64_t margin = 16ull << 30;
         const uint64_t room = free_b > margin ? free_b - margin : 0;
@@ -464,6 +479,8 @@ int launch_work(sa_ctx* c, Work& w, bool timed) {
     P.out_base_pair = w.first_pair;
     P.spill = (uint32_t*)c->d_spill.p;
     P.spill_rows = is_long(c) ? long_dir_rows(c) : 2 * SA_LP;
+    const bool ckpt = is_long(c) && !w.coop && w.schedule == SA_SCHEDULE_TRIANGULAR && w.paired && c->ckpt_rows != 0;
+    if (ckpt) P.spill_rows = long_ckpt_rows_cap(c);
     P.nseq = (uint32_t)c->nseq;
     P.gap = c->gap;
     if (c->phase_timers) {
@@ -483,6 +500,9 @@ int launch_work(sa_ctx* c, Work& w, bool timed) {
         P.spill_rows = kib;
         sa_launch_coop(&P, cgrid, c->compute);
         c->last_kernel = "sa_coop_kernel";
+    } else if (ckpt) {
+        sa_launch_long_ckpt((int)c->ckpt_rows, &P, grid, SA_LDS_PROF_BYTES + 64 + 2 * c->lslot, c->compute);
+        c->last_kernel = c->ckpt_rows == 64 ? "sa_long_ckpt_kernel<64>" : "sa_long_ckpt_kernel<32>";
     } else if (is_long(c) && tri && w.paired) {
         // + 64: rows read table entries two groups ahead, up to 16 bytes past the last profile row; + 2 lslot: the two first sequences
         sa_launch_long_pair(&P, grid, SA_LDS_PROF_BYTES + 64 + 2 * c->lslot, c->compute);
@@ -1168,6 +1188,19 @@ int sa_set_cooperative(sa_ctx* c, int mode) {
     if (!c || mode < -1 || mode > 1) return SA_ERR_ARG;
     if (c->inflight) return SA_ERR_STATE;
     c->coop_mode = mode;
+    c->resident_ready = false;
+    return SA_OK;
+}
+
+int sa_set_long_checkpoint_rows(sa_ctx* c, uint32_t rows) {
+    if (!c || (rows != 0 && rows != 32 && rows != 64)) return SA_ERR_ARG;
+    if (c->inflight) return SA_ERR_STATE;
+    if (c->device != SA_DEVICE_NONE) {
+        SA_HIP_TRY(hipSetDevice(c->device));
+        SA_HIP_TRY(hipStreamSynchronize(c->compute));
+    }
+    c->ckpt_rows = rows;
+    c->spill_grid = 0;             // the scratch areas are laid out per kernel
     c->resident_ready = false;
     return SA_OK;
 }

@@ -1,7 +1,8 @@
 #!/bin/bash
-# tools/build_variant.sh <name> [extra hipcc flags]: builds abtest/libsa_<name>.so from the tree with extra -D flags (for tools/ab.sh)
-name=$1; shift
-C=sequencealigner_amd/csrc
-mkdir -p abtest
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-function -Iinclude "$@" -shared -pthread -o abtest/libsa_$name.so \
-  $C/sa_kernels.hip $C/sa_kernels_pair.hip $C/sa_kernels_long.hip $C/sa_kernels_long_pair.hip $C/sa_kernels_coop.hip $C/sa_format.hip $C/sa_noalloc.hip $C/sa_api.cpp $C/sa_host.cpp
+# tools/build_variant.sh <name> <source file under csrc> [extra hipcc flags]: abtest/libsa_<name>.so = the tree's library
+# with that one source recompiled with the extra flags (for A/B timing through SA_HIP_LIBRARY); `make lib` first.
+name=$1; src=$2; shift 2
+mkdir -p abtest build/var_$name
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function "$@" -c -o build/var_$name/$src.o sequencealigner_amd/csrc/$src || exit 1
+objs=$(ls build/lib/*.o | grep -v "/$src.o")
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -pthread -o abtest/libsa_$name.so $objs build/var_$name/$src.o

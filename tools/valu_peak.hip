@@ -64,6 +64,8 @@ constexpr int CHAINS = 8;
 #define K_MED3 45
 #define K_ANDLIT 46
 #define K_LSHRV 47
+#define K_SCORE_CHAIN 48
+#define K_SCORE_CHAIN_LDS 49
 
 template <int KIND>
 __global__ void __launch_bounds__(256) k_valu(unsigned* out, unsigned long long* cyc, unsigned seed) {
@@ -180,6 +182,13 @@ __global__ void __launch_bounds__(256) k_valu(unsigned* out, unsigned long long*
                 asm volatile("v_lshl_or_b32 %0, %0, 4, %1" : "+v"(f[k]) : "v"(t));
                 d = hb;
             }
+            if (KIND == K_SCORE_CHAIN) {
+                // values-only packed cells: add (independent), three-way maximum whose left operand is the column before
+                unsigned m;
+                asm volatile("v_add_u32 %0, %1, %2" : "=v"(m) : "v"(a[k]), "v"(b));
+                asm volatile("v_pk_maximum3_f16 %0, %1, %0, %2" : "+v"(a[k]) : "v"(m), "v"(d));
+                d = a[k];
+            }
             if (KIND == K_CELL_SIGN) {
                 // add, max3, (sub, alignbit) x2: direction bits = sign bits of (m - h) and (up - h)
                 unsigned m, h, x, y;
@@ -271,6 +280,12 @@ int main() {
         run<K_CMPSDWA>("v_cmp_eq_u32_sdwa", 1, d_out, d_cyc, ncu);
         run<K_MIN3>("v_min3_u32", 1, d_out, d_cyc, ncu);
         run<K_MED3>("v_med3_i32", 1, d_out, d_cyc, ncu);
+        return 0;
+    }
+    if (getenv("VALU_PEAK_SCORE")) {
+        run<K_SCORE_CHAIN>("2 cells: add, pk_max3 chained through the columns (2)", 2, d_out, d_cyc, ncu);
+        run<K_PKMAX3F>("v_pk_maximum3_f16 (8 chains)", 1, d_out, d_cyc, ncu);
+        run<K_CELL_PK3>("4 cells: 2add,2pk_max3,and,or,and_or,bfi,and,lshl_or (10)", 10, d_out, d_cyc, ncu);
         return 0;
     }
     run<K_CELL_SIGN>("cell: add,max3,2x(sub,alignbit) (6)", 6, d_out, d_cyc, ncu);
