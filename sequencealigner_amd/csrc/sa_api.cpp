@@ -401,7 +401,7 @@ size_t spill_bytes_per_wg(const sa_ctx* c) {
     // checkpointing kernel: tile tags (2 x CK KiB), border columns of every strip (256 B per row), every CK-th row of
     // every strip (16 KiB each); row ranges that run unpaired still need the 32-bit kernel's direction rows
     const size_t rows = long_ckpt_rows_cap(c);
-    const size_t ck = (size_t)2 * c->ckpt_rows * 1024 + strips * rows * 256 + (rows / c->ckpt_rows) * strips * 16384;
+    const size_t ck = (size_t)2 * 64 * 1024 + strips * rows * 256 + (rows / c->ckpt_rows) * strips * 16384;     // tiles are 64 rows high
     return std::max(ck, one_matrix);
 }
 
@@ -502,7 +502,7 @@ int launch_work(sa_ctx* c, Work& w, bool timed) {
         c->last_kernel = "sa_coop_kernel";
     } else if (ckpt) {
         sa_launch_long_ckpt((int)c->ckpt_rows, &P, grid, SA_LDS_PROF_BYTES + 64 + 2 * c->lslot, c->compute);
-        c->last_kernel = c->ckpt_rows == 64 ? "sa_long_ckpt_kernel<64>" : "sa_long_ckpt_kernel<32>";
+        c->last_kernel = c->ckpt_rows == 64 ? "sa_long_ckpt_kernel<64, 64>" : "sa_long_ckpt_kernel<32, 64>";
     } else if (is_long(c) && tri && w.paired) {
         // + 64: rows read table entries two groups ahead, up to 16 bytes past the last profile row; + 2 lslot: the two first sequences
         sa_launch_long_pair(&P, grid, SA_LDS_PROF_BYTES + 64 + 2 * c->lslot, c->compute);

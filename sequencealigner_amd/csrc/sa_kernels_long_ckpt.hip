@@ -146,20 +146,23 @@ __device__ __forceinline__ void fill_row_score(uint32_t (&B)[SA_LP], const int o
 __device__ __forceinline__ int lck_ctz64(uint64_t v) { return v ? __builtin_ctzll(v) : 64; }
 
 #ifndef SA_LCK_ROW_BENCH     /* tools/row_bench.hip takes the row functions alone */
-template <int CK>
+// G: rows between checkpoints; T: rows of a tile (a multiple of G).  A lane's tile starts on the checkpoint grid, as
+// low as leaves the row its path stands in inside the tile's last G rows: with T > G a path then covers at least
+// T - G rows of every tile it goes through upwards, where tiles on a grid of their own height are entered anywhere.
+template <int G, int T>
 __global__ void __launch_bounds__(64, 4) sa_long_ckpt_kernel(const SaPepParams P) {
-    static_assert(CK % 16 == 0 && 64 % CK == 0, "checkpoint rows: 16, 32 or 64");
+    static_assert(G % 16 == 0 && 64 % G == 0 && T % G == 0 && T % 8 == 0 && T <= 64, "checkpoint rows 16, 32 or 64; tile rows a multiple, at most 64");
     extern __shared__ __align__(16) uint8_t smem[];
     int32_t* const prof = reinterpret_cast<int32_t*>(smem);
     uint8_t* const pseq = smem + SA_LDS_PROF_BYTES + 64;      // the two shared first sequences, lslot bytes each
     const int lane = threadIdx.x;
     const uint32_t rows_cap = P.spill_rows;                    // rows of border columns and checkpoints: a multiple of 64
     const uint32_t strips_cap = P.lslot >> 6;
-    // per-workgroup scratch, dwords: tile tags (2 halves x CK rows x 256) | border columns (strips x rows x 64) |
+    // per-workgroup scratch, dwords: tile tags (2 halves x T rows x 256) | border columns (strips x rows x 64) |
     // checkpoints (row blocks x strips x 64 columns x 64 lanes)
-    const size_t tile_dw = (size_t)2 * CK * 256;
+    const size_t tile_dw = (size_t)2 * T * 256;
     const size_t bcol_dw = (size_t)strips_cap * rows_cap * 64;
-    const size_t ckp_dw = (size_t)(rows_cap / CK) * strips_cap * 4096;
+    const size_t ckp_dw = (size_t)(rows_cap / G) * strips_cap * 4096;
     uint32_t* const tile = P.spill + (size_t)blockIdx.x * (tile_dw + bcol_dw + ckp_dw);
     uint32_t* const bcol = tile + tile_dw;
     uint32_t* const ckp = bcol + bcol_dw;
@@ -289,13 +292,15 @@ __global__ void __launch_bounds__(64, 4) sa_long_ckpt_kernel(const SaPepParams P
                 const int oend = (gend + 1) >> 1;     // octets of a row
                 // full_tag: the strip is 64 columns wide; cap_tag: a half's last column lies in this strip, so the rows
                 // look for the lane's last row (elsewhere the loop carries no such test and no column pick).
-                // Rows go in blocks of four inside runs of CK rows.  Every block issues two loads (next residues, next
+                // Rows go in blocks of four inside runs of G rows.  Every block issues two loads (next residues, next
                 // border values) and one store (its last-column values; in the last strip nobody reads them), always, so
                 // that the wait for the loads at the top of the next block is a count that leaves the store in flight;
-                // the checkpoint's sixteen stores stand after the run.
+                // the checkpoint's sixteen stores stand after the run, outside the loop of the blocks.  (With the
+                // checkpoint under a condition inside that loop the compiler waits for everything in flight at the top
+                // of every block: 13 % more time for the sweep.)
                 auto sweep = [&](auto full_tag, auto cap_tag) {
-                for (int rb = 0; rb < maxlen; rb += CK) {
-                    const int rend = min(rb + CK, maxlen);
+                for (int rb = 0; rb < maxlen; rb += G) {
+                    const int rend = min(rb + G, maxlen);
                     for (int r = rb; r < rend; r += 4) {
                         const uint32_t nres = residues4(r + 4);
                         const uint4 nbord = border4(r + 4);
@@ -324,9 +329,9 @@ __global__ void __launch_bounds__(64, 4) sa_long_ckpt_kernel(const SaPepParams P
                         bres = nres;
                         bord = nbord;
                     }
-                    if (rb + CK < maxlen) {
+                    if (rb + G < maxlen) {
                         // checkpoint: the row just done, every column, low 16 bits of the values
-                        uint4* ck = reinterpret_cast<uint4*>(ckp + ((size_t)((rb / CK) * strips_cap + s) * 16) * 256) + lane;
+                        uint4* ck = reinterpret_cast<uint4*>(ckp + ((size_t)((rb / G) * strips_cap + s) * 16) * 256) + lane;
 #pragma unroll
                         for (int c4 = 0; c4 < 16; c4++)
                             ck[(size_t)c4 * 64] = make_uint4(lck_pk_add(R[4 * c4], base12), lck_pk_add(R[4 * c4 + 1], base12),
@@ -384,11 +389,12 @@ __global__ void __launch_bounds__(64, 4) sa_long_ckpt_kernel(const SaPepParams P
                 build_profile(s, true);
                 const uint4* bin = reinterpret_cast<const uint4*>(bcol + (size_t)max(s - 1, 0) * rows_cap * 64) + lane;
                 while (__any(in0 || in1)) {
-                    // the tile this lane fills: the lower of the tiles its two paths stand in
-                    const int k0 = in0 ? (wi[0] - 1) / CK : -1, k1 = in1 ? (wi[1] - 1) / CK : -1;
-                    const int kl = max(max(k0, k1), 0);
-                    const int r0 = kl * CK;
-                    const bool t0 = in0 && k0 == kl, t1 = in1 && k1 == kl;        // halves that walk this tile
+                    // the tile this lane fills: T rows from a checkpoint, placed so that the lower of its two paths stands
+                    // in the tile's last G rows (or, near the top of the matrix, in the rows there are)
+                    const int rlow = max(in0 ? wi[0] - 1 : -1, in1 ? wi[1] - 1 : -1);          // -1: neither path is in the strip
+                    const int kl = max(rlow / G - (T / G - 1), 0);                              // checkpoint grid index of the tile's first row
+                    const int r0 = kl * G;
+                    const bool t0 = in0 && wi[0] - 1 >= r0, t1 = in1 && wi[1] - 1 >= r0;        // halves that walk this tile
                     // rows 0 .. tneed of the tile are wanted, columns 0 .. jneed - 1 of the strip
                     const int tneed = max(t0 ? wi[0] - 1 - r0 : -1, t1 ? wi[1] - 1 - r0 : -1);
                     const int jneed = max(t0 ? wj[0] - cbase : 0, t1 ? wj[1] - cbase : 0);
@@ -422,7 +428,7 @@ __global__ void __launch_bounds__(64, 4) sa_long_ckpt_kernel(const SaPepParams P
 #pragma unroll
                     for (int w = 0; w < 8; w++) e[w] = 0;
                     uint32_t* const drowA = tile + (size_t)lane * 4;
-                    uint32_t* const drowB = drowA + (size_t)CK * 256;
+                    uint32_t* const drowB = drowA + (size_t)T * 256;
                     auto residues4 = [&](int r) -> uint32_t {
                         return *reinterpret_cast<const uint32_t*>(bslot + min(r, slot_last - 3));
                     };
@@ -486,7 +492,7 @@ __global__ void __launch_bounds__(64, 4) sa_long_ckpt_kernel(const SaPepParams P
                     int tc0 = t0 ? wi[0] - 1 - r0 : -1, tc1 = t1 ? wi[1] - 1 - r0 : -1;      // the row of the tile a path stands in, -1: none
                     const uint32_t voff = (uint32_t)lane * 16;
                     const uint8_t* const tile_a = reinterpret_cast<const uint8_t*>(tile);
-                    const uint8_t* const tile_b = tile_a + (size_t)CK * 1024;
+                    const uint8_t* const tile_b = tile_a + (size_t)T * 1024;
                     const uint8_t* const resp = bslot + r0;
                     sa_u32x4v a0x, a1x, a2x, a3x, a4x, a5x, a6x, a7x, b0x, b1x, b2x, b3x, b4x, b5x, b6x, b7x;
                     sa_u32x2v rx;
@@ -586,9 +592,9 @@ __global__ void __launch_bounds__(64, 4) sa_long_ckpt_kernel(const SaPepParams P
 }
 
 extern "C" void sa_launch_long_ckpt(int ck_rows, const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream) {
-    if (ck_rows == 64)
-        hipLaunchKernelGGL((sa_long_ckpt_kernel<64>), dim3(grid), dim3(64), lds_bytes, stream, *p);
+    if (ck_rows == 32)
+        hipLaunchKernelGGL((sa_long_ckpt_kernel<32, 64>), dim3(grid), dim3(64), lds_bytes, stream, *p);
     else
-        hipLaunchKernelGGL((sa_long_ckpt_kernel<32>), dim3(grid), dim3(64), lds_bytes, stream, *p);
+        hipLaunchKernelGGL((sa_long_ckpt_kernel<64, 64>), dim3(grid), dim3(64), lds_bytes, stream, *p);
 }
 #endif

@@ -182,10 +182,10 @@ def test_long_sequences_whose_matrix_values_pass_16_bits():
     al.set_cooperative(-1)
     al.upload(seqs)
     rec = al.align(sa.TRIANGULAR)
-    assert al.last_kernel() == "sa_long_ckpt_kernel<64>"
+    assert al.last_kernel() == "sa_long_ckpt_kernel<64, 64>"
     _check_pairs(al, rec, _tri_pairs(len(seqs), 0, len(seqs) - 1))
     # the same through the other two forms of the packed kernel: checkpoints every 32 rows, whole direction matrix
-    for rows, kernel in ((32, "sa_long_ckpt_kernel<32>"), (0, "sa_long_pair_kernel<4>")):
+    for rows, kernel in ((32, "sa_long_ckpt_kernel<32, 64>"), (0, "sa_long_pair_kernel<4>")):
         al.set_long_checkpoint_rows(rows)
         assert np.array_equal(al.align(sa.TRIANGULAR), rec)
         assert al.last_kernel() == kernel
@@ -342,7 +342,7 @@ def test_full_size_protein_set_sampled_against_oracle():
     assert total == n * (n - 1) // 2 == 49995000
     al.prepare_resident(sa.TRIANGULAR, 0, rows)
     al.run_resident()
-    assert al.last_kernel() == "sa_long_ckpt_kernel<64>"
+    assert al.last_kernel() == "sa_long_ckpt_kernel<64, 64>"
     rng = random.Random(77)
     picks = [(0, 1), (0, n - 1), (n - 2, n - 1), (n - 3, n - 2), (1, 2)]
     while len(picks) < 340:
@@ -489,9 +489,9 @@ def test_long_paired_and_unpaired_kernels_give_identical_records(n, lo, hi, seed
     al.set_cooperative(-1)
     assert any(it[5] != 0xFFFFFFFF for it in al.work_items(sa.TRIANGULAR, 0, n - 1).tolist())
     paired = al.align(sa.TRIANGULAR)
-    assert al.last_kernel() == "sa_long_ckpt_kernel<64>"
+    assert al.last_kernel() == "sa_long_ckpt_kernel<64, 64>"
     # the packed kernel's other forms: a checkpoint every 32 rows; two direction bits stored for every cell
-    for rows, kernel in ((32, "sa_long_ckpt_kernel<32>"), (0, "sa_long_pair_kernel<4>")):
+    for rows, kernel in ((32, "sa_long_ckpt_kernel<32, 64>"), (0, "sa_long_pair_kernel<4>")):
         al.set_long_checkpoint_rows(rows)
         assert np.array_equal(al.align(sa.TRIANGULAR), paired), rows
         assert al.last_kernel() == kernel
@@ -871,7 +871,7 @@ def test_library_names_the_kernel_it_ran():
     assert bl.last_kernel() == "sa_coop_kernel"          # 3160 pairs: fewer than 384 per CU
     bl.set_cooperative(-1)
     bl.align(sa.TRIANGULAR)
-    assert bl.last_kernel() == "sa_long_ckpt_kernel<64>"
+    assert bl.last_kernel() == "sa_long_ckpt_kernel<64, 64>"
     bl.set_long_checkpoint_rows(0)
     bl.align(sa.TRIANGULAR)
     assert bl.last_kernel() == "sa_long_pair_kernel<4>"
