@@ -293,10 +293,14 @@ def d2h_measurement(sa, csv_path, cells):
     """The bench workload with every record copied to pinned host memory (sa_submit / sa_next, two submissions in
     flight, nothing formatted or written): the reference's "without write" mode (MODE_WRITE 0, src/main.c:111-116)."""
     rep = sa.run_csv(csv_path, None, sa.TRIANGULAR)
-    return {"what": "CSV ingest + upload + kernels + every record over PCIe to pinned host memory, no formatting, no write",
+    full = sa.run_csv(csv_path, None, sa.TRIANGULAR, compact_records=0)
+    return {"what": "CSV ingest + upload + kernels + every record over PCIe to pinned host memory, no formatting, no write; records "
+                    "packed on the device first (header + one byte per row of the pair's second sequence, 4-byte aligned)",
             "seconds": round(rep.seconds, 4), "gcups": round(cells / rep.seconds / 1e9, 1),
             "pairs_per_s": round(rep.pairs / rep.seconds, 1),
-            "record_gb_per_s": round(rep.pairs * 64 / rep.seconds / 1e9, 2),
+            "record_bytes": rep.record_bytes, "record_gb_per_s": round(rep.record_bytes / rep.seconds / 1e9, 2),
+            "full_stride_records": {"seconds": round(full.seconds, 4), "record_bytes": full.record_bytes,
+                                    "gcups": round(cells / full.seconds / 1e9, 1)},
             "seconds_ingest": round(rep.seconds_ingest, 4), "seconds_upload": round(rep.seconds_upload, 4),
             "seconds_gpu_wait": round(rep.seconds_gpu_wait, 4)}
 

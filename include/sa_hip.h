@@ -118,8 +118,27 @@ int sa_shard_rows(const sa_ctx* ctx, int schedule, uint32_t parts, uint64_t* bou
  * until the oldest submission is complete and hands out its records, which
  * stay valid until sa_release.  Two submissions may be in flight. */
 int sa_submit(sa_ctx* ctx, int schedule, uint64_t row_begin, uint64_t row_end);
+/* Optional, part of the set-up (the reference allocates its batch arrays before its timing window opens,
+ * src/main.c:25-30): device and pinned host buffers of both in-flight slots for submissions of up to `npairs` pairs of
+ * sequences of up to `longest_sequence` residues.  Without it the buffers are allocated, and grown, by the submissions
+ * themselves (a pinned allocation of 100 MB takes tens of milliseconds). */
+int sa_reserve_submission(sa_ctx* ctx, uint64_t npairs, uint32_t longest_sequence);
 int sa_next(sa_ctx* ctx, const uint8_t** records, uint64_t* first_pair, uint64_t* npairs);
 int sa_release(sa_ctx* ctx);
+
+/* ---- records without their padding.  A record has the context's stride, sized for the longest uploaded sequence; most
+ * pairs need less (one code per row of THEIR second sequence).  With sa_set_compact_records(ctx, 1) a submission's records
+ * are packed on the device before they travel to the host: pair after pair in canonical order, each cut to
+ * sa_compact_record_size(second sequence) = header + codes, rounded up to 4 bytes; sa_next then hands out that packed
+ * stream (sa_compact_bytes of the submission's rows long).  Pair (i, j) of a submission that starts at row r starts at
+ * sa_compact_pair_offset(schedule, i, j) - sa_compact_pair_offset(schedule, r, r + 1); sa_expand_record reads a packed
+ * record when it is given the record's own size as its stride.  The reference moves whole 280-byte Alignment structs
+ * from workers to writer (include/common.h:19-29, include/thread.h:35-42); over PCIe the bytes are the cost.
+ * Default: off (records of sa_record_stride bytes each). */
+int sa_set_compact_records(sa_ctx* ctx, int enable);
+uint32_t sa_compact_record_size(const sa_ctx* ctx, uint64_t second_sequence);
+uint64_t sa_compact_pair_offset(const sa_ctx* ctx, int schedule, uint64_t i, uint64_t j);
+uint64_t sa_compact_bytes(const sa_ctx* ctx, int schedule, uint64_t row_begin, uint64_t row_end);
 
 /* ---- rows of CSV text written on the GPU.  Stands for the formatting the reference does on its main
  * thread after a batch (buffer_output, include/csv.h:84-141; init_format, include/csv.h:38-82): a

@@ -48,6 +48,8 @@ typedef struct {
     char scoring_matrix_file[4096];   /* SA_SCORING_MATRIX: file with the 20x20 substitution matrix (sa_load_matrix_file); empty = the
                                          reference's BLOSUM50 literal (include/scoring.h:16-36) */
     int32_t cooperative;              /* SA_COOPERATIVE: sa_set_cooperative() of every context; default 0 (by pair count) */
+    int32_t compact_records;          /* SA_COMPACT_RECORDS: 1 (default): records that travel to the host (host formatting, MODE_WRITE 0)
+                                         are packed on the device first (sa_set_compact_records); 0: records of the full stride */
 } sa_settings;
 
 typedef struct {
@@ -69,6 +71,7 @@ typedef struct {
     double device_wait[8];
     double device_format[8];
     double device_write[8];
+    uint64_t record_bytes;            /* bytes of records copied from the devices to the host (0 when the GPUs wrote the text) */
 } sa_run_report;
 
 void sa_settings_default(sa_settings* st);

@@ -71,6 +71,7 @@ class Settings(C.Structure):
         ("device_format", C.c_int32),
         ("scoring_matrix_file", C.c_char * 4096),
         ("cooperative", C.c_int32),
+        ("compact_records", C.c_int32),
     ]
 
 
@@ -101,6 +102,7 @@ class RunReport(C.Structure):
         ("device_wait", C.c_double * 8),
         ("device_format", C.c_double * 8),
         ("device_write", C.c_double * 8),
+        ("record_bytes", C.c_uint64),
     ]
 
 
@@ -124,6 +126,7 @@ SIGNATURES = {
     "sa_record_row_bytes": (C.c_uint32, [C.c_void_p]),
     "sa_shard_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.POINTER(C.c_uint64)]),
     "sa_submit": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64]),
+    "sa_reserve_submission": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32]),
     "sa_next": (C.c_int, [C.c_void_p, C.POINTER(_u8p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "sa_release": (C.c_int, [C.c_void_p]),
     "sa_prepare_resident": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64]),
@@ -136,6 +139,10 @@ SIGNATURES = {
     "sa_set_pairing": (C.c_int, [C.c_void_p, C.c_int]),
     "sa_set_cooperative": (C.c_int, [C.c_void_p, C.c_int]),
     "sa_set_long_checkpoint_rows": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "sa_set_compact_records": (C.c_int, [C.c_void_p, C.c_int]),
+    "sa_compact_record_size": (C.c_uint32, [C.c_void_p, C.c_uint64]),
+    "sa_compact_pair_offset": (C.c_uint64, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64]),
+    "sa_compact_bytes": (C.c_uint64, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64]),
     "sa_set_text_layout": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sa_upload_passthrough": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.c_uint64]),
     "sa_submit_text": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64]),
@@ -340,6 +347,45 @@ class Aligner:
 
     def release(self):
         _check(self._lib.sa_release(self._ctx))
+
+    # -- records without their padding
+    def set_compact_records(self, enable):
+        """Submissions hand out packed records: each cut to its own second sequence, 4-byte aligned, in pair order."""
+        _check(self._lib.sa_set_compact_records(self._ctx, 1 if enable else 0))
+
+    def compact_record_size(self, second_sequence):
+        return self._lib.sa_compact_record_size(self._ctx, second_sequence)
+
+    def compact_pair_offset(self, schedule, i, j):
+        return self._lib.sa_compact_pair_offset(self._ctx, schedule, i, j)
+
+    def compact_bytes(self, schedule, r0, r1):
+        return self._lib.sa_compact_bytes(self._ctx, schedule, r0, r1)
+
+    def next_compact(self, schedule, r0, r1):
+        """The oldest submission's packed records as a flat uint8 view (compact mode), plus its first pair index."""
+        rec = _u8p()
+        first = C.c_uint64()
+        n = C.c_uint64()
+        _check(self._lib.sa_next(self._ctx, C.byref(rec), C.byref(first), C.byref(n)))
+        nbytes = self.compact_bytes(schedule, r0, r1)
+        if n.value == 0 or nbytes == 0:
+            return np.zeros(0, dtype=np.uint8), first.value
+        return np.ctypeslib.as_array(rec, shape=(nbytes,)), first.value
+
+    def align_compact(self, schedule, r0=0, r1=None):
+        """Align rows [r0, r1) with compact records on and return a copy of the packed stream."""
+        if r1 is None:
+            r1 = self.rows(schedule)
+        self.set_compact_records(True)
+        try:
+            self.submit(schedule, r0, r1)
+            rec, _ = self.next_compact(schedule, r0, r1)
+            out = rec.copy()
+            self.release()
+        finally:
+            self.set_compact_records(False)
+        return out
 
     def align(self, schedule, r0=0, r1=None):
         """Align rows [r0, r1) and return a copy of their records."""

@@ -30,6 +30,8 @@ extern "C" void sa_launch_long_pair(const SaPepParams* p, unsigned grid, unsigne
 extern "C" void sa_launch_long_ckpt(int ck_rows, const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream);
 extern "C" void sa_launch_coop(const SaPepParams* p, unsigned grid, hipStream_t stream);
 extern "C" void sa_launch_long(int mode, const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream);
+extern "C" void sa_launch_compact(int schedule, const uint8_t* out, uint8_t* packed, const uint64_t* cp, const uint64_t* cq,
+                                  uint64_t nseq, uint64_t r0, uint64_t r1, uint32_t stride, hipStream_t stream);
 
 namespace {
 
@@ -109,6 +111,10 @@ struct Work {                 // one submitted (or prepared) row range
     PinBuf items_pin;          // the work list on its way to the device (pinned: the copy needs no wait)
     PinBuf status_pin;         // the kernels' status word, copied back behind every launch
     bool text_mode = false;
+    DevBuf packed;             // compact submissions: the records without their padding, as they travel to the host
+    bool compact = false;
+    uint64_t packed_bytes = 0;
+    uint64_t r0 = 0, r1 = 0;
 };
 
 }  // namespace
@@ -127,6 +133,10 @@ struct sa_ctx {
     int64_t sprime_min = 0, sprime_max = 0;   // range of S' = S - 2*gap over the table: decides whether packed cells fit
     uint32_t bucket_width = 1;
     int coop_mode = 0;                 // wave-per-pair kernel for long sequences: 0 = when a submission has few pairs, 1 always, -1 never
+    bool compact = false;              // sa_set_compact_records: submissions hand out packed records
+    std::vector<uint64_t> cp, cq;      // prefix arrays of the packed record sizes (sa_compact.hip), built with the upload
+    DevBuf d_cp, d_cq;
+    bool compact_on_device = false;
     uint32_t ckpt_rows = 64;           // paired long-sequence kernel: rows between checkpoints (32 or 64); 0 = the kernel that stores a whole direction matrix
     uint32_t bucket_width_forced = 0;  // sa_set_bucket_width: 0 = from the number of sequences per length
     // sequences (host mirror)
@@ -190,6 +200,37 @@ void ensure_suffix(sa_ctx* c) {
     if (c->len_suffix.size() == c->nseq + 1) return;
     c->len_suffix.assign(c->nseq + 1, 0);
     for (uint64_t s = c->nseq; s-- > 0;) c->len_suffix[s] = c->len_suffix[s + 1] + c->len[s];
+}
+
+// packed record of a pair whose second sequence has `len` residues: header + one code per row, rounded up to 4 bytes
+inline uint32_t packed_record_bytes(const sa_ctx* c, uint32_t len) {
+    const uint32_t header = c->row_bytes == 1 ? SA_REC_HEADER_BYTES : SA_LONG_HEADER_BYTES;
+    return (header + c->row_bytes * len + 3u) & ~3u;
+}
+// cp[s] = packed bytes of the records whose second sequence is one of 0 .. s-1; cq[i] = packed bytes of the
+// TRIANGULAR rows of first sequences 0 .. i-1 (row i holds second sequences i+1 .. n-1)
+void build_compact_tables(sa_ctx* c) {
+    const uint64_t n = c->nseq;
+    c->cp.assign(n + 2, 0);
+    for (uint64_t s = 0; s < n; s++) c->cp[s + 1] = c->cp[s] + packed_record_bytes(c, c->len[s]);
+    c->cp[n + 1] = c->cp[n];
+    c->cq.assign(n + 1, 0);
+    for (uint64_t i = 0; i < n; i++) c->cq[i + 1] = c->cq[i] + (i + 1 <= n ? c->cp[n] - c->cp[i + 1] : 0);
+    c->compact_on_device = false;
+}
+int ensure_compact_on_device(sa_ctx* c) {
+    if (c->compact_on_device) return SA_OK;
+    int rc;
+    if ((rc = c->d_cp.reserve(c->cp.size() * 8)) || (rc = c->d_cq.reserve(c->cq.size() * 8))) return rc;
+    SA_HIP_TRY(hipMemcpy(c->d_cp.p, c->cp.data(), c->cp.size() * 8, hipMemcpyHostToDevice));
+    SA_HIP_TRY(hipMemcpy(c->d_cq.p, c->cq.data(), c->cq.size() * 8, hipMemcpyHostToDevice));
+    c->compact_on_device = true;
+    return SA_OK;
+}
+// byte offset of pair (i, j) in the packed stream of the whole schedule
+inline uint64_t compact_offset(const sa_ctx* c, int schedule, uint64_t i, uint64_t j) {
+    if (schedule == SA_SCHEDULE_ADJACENT) return c->cp[j] - c->cp[1];          // pair (i, i + 1): second sequences 1 .. i come before
+    return c->cq[i] + c->cp[j] - c->cp[i + 1];
 }
 
 int ensure_triangular(sa_ctx* c) {
@@ -600,7 +641,7 @@ int init_events(Work& w) {
 void free_work(Work& w) {
     w.items.release(); w.out.release(); w.counter.release(); w.host.release();
     w.lens.release(); w.offs.release(); w.text.release(); w.total.release(); w.scan_tmp.release();
-    w.host_total.release(); w.items_pin.release(); w.status_pin.release();
+    w.host_total.release(); w.items_pin.release(); w.status_pin.release(); w.packed.release();
     if (w.kernel_done) (void)hipEventDestroy(w.kernel_done);
     if (w.copied) (void)hipEventDestroy(w.copied);
     if (w.t0) (void)hipEventDestroy(w.t0);
@@ -721,7 +762,7 @@ void sa_destroy(sa_ctx* c) {
     c->d_codes.release(); c->d_len.release(); c->d_codes_t.release(); c->d_fi_sorted.release();
     c->d_len_sorted.release(); c->d_bucket_base.release(); c->d_cursor.release(); c->d_sprime.release();
     c->d_spill.release(); c->d_bcol.release(); c->d_codes_s.release(); c->d_coop.release();
-    c->d_other.release(); c->d_other_off.release();
+    c->d_other.release(); c->d_other_off.release(); c->d_cp.release(); c->d_cq.release();
     c->text_ring[0].release(); c->text_ring[1].release();
     c->d_phase.release();
     if (c->compute) (void)hipStreamDestroy(c->compute);
@@ -794,6 +835,7 @@ int sa_upload(sa_ctx* c, const uint8_t* codes, const uint64_t* offs, const uint3
     });
     c->len_suffix.clear();
     ensure_suffix(c);      // here, not lazily: sa_cell_count / sa_shard_rows take a const context and may run on any thread
+    build_compact_tables(c);
     if (c->device == SA_DEVICE_NONE) {
         // no device to read the slots back from: a host-only context keeps them itself
         c->slots_host.assign((size_t)(nseq + 2) * lslot, SA_PAD_CODE);
@@ -893,6 +935,7 @@ int sa_clone_sequences(sa_ctx* dst, sa_ctx* src) {
     dst->spill_grid = 0;
     dst->lslot = src->lslot; dst->row_bytes = src->row_bytes; dst->stride = src->stride;
     dst->len = src->len; dst->len_suffix = src->len_suffix; dst->slots_host = src->slots_host;
+    dst->cp = src->cp; dst->cq = src->cq; dst->compact_on_device = false;
     dst->resident_ready = false;
     dst->tri_ready = false;
     const bool dev = dst->device != SA_DEVICE_NONE;
@@ -945,13 +988,33 @@ int sa_submit(sa_ctx* c, int schedule, uint64_t r0, uint64_t r1) {
     }
     SA_HIP_TRY(hipSetDevice(c->device));
     Work& w = c->slots[head];
-    int rc = prepare_work(c, w, schedule, r0, r1, true);
+    const bool compact = c->compact;
+    int rc = prepare_work(c, w, schedule, r0, r1, !compact);
     if (rc) return rc;
+    w.compact = compact;
+    w.r0 = r0; w.r1 = r1;
+    w.packed_bytes = 0;
+    if (compact && w.npairs) {
+        // what leaves the device: the records cut to their own lengths (sa_compact.hip)
+        if ((rc = ensure_compact_on_device(c))) return rc;
+        w.packed_bytes = schedule == SA_SCHEDULE_ADJACENT ? c->cp[r1 + 1] - c->cp[r0 + 1] : c->cq[r1] - c->cq[r0];
+        // buffers sized as for full records: the packed size changes from submission to submission with the lengths of
+        // the sequences in it, and a pinned buffer that has to grow is freed and allocated again (tens of milliseconds)
+        if ((rc = w.packed.reserve(std::max<size_t>(16, w.npairs * (size_t)c->stride)))) return rc;
+        if ((rc = w.host.reserve(std::max<size_t>(16, w.npairs * (size_t)c->stride)))) return rc;
+    }
     if ((rc = launch_work(c, w, false))) return rc;
+    if (compact && w.npairs) {
+        sa_launch_compact(schedule, (const uint8_t*)w.out.p, (uint8_t*)w.packed.p, (const uint64_t*)c->d_cp.p, (const uint64_t*)c->d_cq.p,
+                          c->nseq, r0, r1, c->stride, c->compute);
+        SA_HIP_TRY(hipGetLastError());
+    }
     SA_HIP_TRY(hipEventRecord(w.kernel_done, c->compute));
     SA_HIP_TRY(hipStreamWaitEvent(c->copy, w.kernel_done, 0));
-    if (w.npairs)
-        SA_HIP_TRY(hipMemcpyAsync(w.host.p, w.out.p, w.npairs * (size_t)c->stride, hipMemcpyDeviceToHost, c->copy));
+    if (w.npairs) {
+        if (compact) SA_HIP_TRY(hipMemcpyAsync(w.host.p, w.packed.p, w.packed_bytes, hipMemcpyDeviceToHost, c->copy));
+        else SA_HIP_TRY(hipMemcpyAsync(w.host.p, w.out.p, w.npairs * (size_t)c->stride, hipMemcpyDeviceToHost, c->copy));
+    }
     SA_HIP_TRY(hipEventRecord(w.copied, c->copy));
     w.busy = true;
     w.text_mode = false;
@@ -1190,6 +1253,46 @@ int sa_set_cooperative(sa_ctx* c, int mode) {
     c->coop_mode = mode;
     c->resident_ready = false;
     return SA_OK;
+}
+
+int sa_reserve_submission(sa_ctx* c, uint64_t npairs, uint32_t longest_sequence) {
+    if (!c || npairs == 0 || longest_sequence == 0 || longest_sequence > c->max_len) return SA_ERR_ARG;
+    if (c->device == SA_DEVICE_NONE) return SA_ERR_STATE;
+    if (c->inflight) return SA_ERR_STATE;
+    SA_HIP_TRY(hipSetDevice(c->device));
+    const bool lng = longest_sequence > SA_LP;
+    const size_t stride = lng ? (SA_LONG_HEADER_BYTES + 2 * (size_t)longest_sequence + 15u) & ~(size_t)15
+                              : (SA_REC_HEADER_BYTES + (size_t)longest_sequence + 15u) & ~(size_t)15;
+    const size_t bytes = npairs * stride;
+    for (Work& w : c->slots) {
+        int rc;
+        if ((rc = w.out.reserve(bytes)) || (rc = w.host.reserve(bytes))) return rc;
+        if (c->compact && (rc = w.packed.reserve(bytes))) return rc;
+    }
+    return SA_OK;
+}
+
+int sa_set_compact_records(sa_ctx* c, int enable) {
+    if (!c) return SA_ERR_ARG;
+    if (c->inflight) return SA_ERR_STATE;
+    c->compact = enable != 0;
+    return SA_OK;
+}
+
+uint32_t sa_compact_record_size(const sa_ctx* c, uint64_t second_sequence) {
+    if (!c || second_sequence >= c->nseq) return 0;
+    return packed_record_bytes(c, c->len[second_sequence]);
+}
+
+uint64_t sa_compact_pair_offset(const sa_ctx* c, int schedule, uint64_t i, uint64_t j) {
+    if (!c || i >= j || j >= c->nseq || c->cp.size() != c->nseq + 2) return 0;
+    if (schedule == SA_SCHEDULE_ADJACENT && j != i + 1) return 0;
+    return compact_offset(c, schedule, i, j);
+}
+
+uint64_t sa_compact_bytes(const sa_ctx* c, int schedule, uint64_t r0, uint64_t r1) {
+    if (!c || r1 <= r0 || r1 > sa_schedule_rows(c, schedule) || c->cp.size() != c->nseq + 2) return 0;
+    return schedule == SA_SCHEDULE_ADJACENT ? c->cp[r1 + 1] - c->cp[r0 + 1] : c->cq[r1] - c->cq[r0];
 }
 
 int sa_set_long_checkpoint_rows(sa_ctx* c, uint32_t rows) {

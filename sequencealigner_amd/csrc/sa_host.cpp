@@ -289,6 +289,7 @@ void sa_settings_default(sa_settings* st) {
     st->pairs_per_submit = 0;
     st->pairing = 1;
     st->device_format = 1;
+    st->compact_records = 1;
 }
 
 static bool parse_c_string(const char* p, char* out, size_t cap) {
@@ -345,6 +346,7 @@ int sa_settings_load(sa_settings* st, const char* path) {
         else if (k == "SA_SCHEDULE") { if (num(x)) st->schedule = (int32_t)x; }
         else if (k == "SA_NUM_DEVICES") { if (num(x)) st->num_devices = (int32_t)x; }
         else if (k == "SA_COOPERATIVE") { if (num(x)) st->cooperative = (int32_t)x; }
+        else if (k == "SA_COMPACT_RECORDS") { if (num(x)) st->compact_records = (int32_t)x; }
         else if (k == "SA_SCORING_MATRIX") { if (!parse_c_string(v, st->scoring_matrix_file, sizeof(st->scoring_matrix_file))) st->scoring_matrix_file[0] = 0; }
     }
     fclose(f);
@@ -441,10 +443,23 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
         if (rc) { err = msg; return fail(rc); }
         S = matrix;
     }
+    // rows of more columns than the device formatter's layout holds are formatted on the host (any column count)
+    const bool text_mode = st->mode_write && st->device_format && L.ncols <= 32;
+    const bool compact = !text_mode && st->compact_records != 0;       // records travel to the host: without their padding
     for (int d = 0; d < ndev; d++) {
         rc = sa_init(&ctx[(size_t)d], S, st->gap_penalty, max_len, st->devices[d]);
         if (rc == SA_OK) rc = sa_set_pairing(ctx[(size_t)d], st->pairing);
         if (rc == SA_OK) rc = sa_set_cooperative(ctx[(size_t)d], st->cooperative);
+        if (rc == SA_OK) rc = sa_set_compact_records(ctx[(size_t)d], compact ? 1 : 0);
+        if (rc == SA_OK && !text_mode) {
+            // the record buffers of both slots, as part of the set-up (at most 256 MiB each here; larger submissions
+            // grow them when they come)
+            const uint64_t cap0 = st->pairs_per_submit ? st->pairs_per_submit
+                                                       : (uint64_t)st->batch_size * (st->schedule == SA_SCHEDULE_TRIANGULAR ? 64 : 4);
+            const uint64_t per_pair = max_len > 64 ? 16 + 2 * (uint64_t)max_len + 16 : 8 + (uint64_t)max_len + 16;
+            const uint64_t pairs0 = std::max<uint64_t>(1, std::min<uint64_t>(cap0, (256ull << 20) / per_pair));
+            rc = sa_reserve_submission(ctx[(size_t)d], pairs0, max_len);
+        }
         if (rc) { cleanup(); return fail(rc); }
     }
 
@@ -506,8 +521,6 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
     if (n >= 2) {
         const double tu0 = now_s();
         const int schedule = st->schedule;
-        // rows of more columns than the device formatter's layout holds are formatted on the host (any column count)
-        const bool text_mode = st->mode_write && st->device_format && L.ncols <= 32;
         // The first context takes the sequences from the host (validation, slots, length tables; for TRIANGULAR the
         // bucket order and cursor table; for rows written on the GPU the layout and the pass-through text); the
         // others clone it device to device, all at once.
@@ -610,6 +623,7 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
         std::atomic<bool> write_failed(false);
         std::atomic<uint64_t> written(0);
         std::atomic<uint64_t> chunks_done(0);
+        std::atomic<uint64_t> record_bytes(0);
 
         // ---- per device: one thread submits its chunks (work lists are built there), one drains them in order
         struct Dev {
@@ -692,6 +706,7 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
                     chunks_done.fetch_add(1);
                     continue;
                 }
+                record_bytes.fetch_add(compact ? sa_compact_bytes(c, schedule, chunks[k].r0, chunks[k].r1) : np * (uint64_t)stride);
                 if (st->mode_write && np) {
                     // the previous chunk's writer works on the other buffer set: it is joined only when this chunk's
                     // rows are ready, so writing overlaps formatting
@@ -713,11 +728,17 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
                             while (sa_pair_index(c, schedule, i + 1) <= ix) i++;
                             j = i + 1 + (ix - sa_pair_index(c, schedule, i));
                         }
+                        // packed records: where this slice's first record starts inside the submission
+                        uint64_t at = 0;
+                        if (compact) at = sa_compact_pair_offset(c, schedule, i, j) - sa_compact_pair_offset(c, schedule, chunks[k].r0, chunks[k].r0 + 1);
                         for (uint64_t q = lo; q < hi; q++) {
                             const Row& r1 = tab.rows[i];
                             const Row& r2 = tab.rows[j];
                             sa_alignment_stats s;
-                            if (sa_expand_record(recs + q * (size_t)stride, stride, row_bytes, r1.seq, r1.len, r2.seq, r2.len, a1.data(), a2.data(), &s) != SA_OK) {
+                            const uint32_t rec_bytes = compact ? sa_compact_record_size(c, j) : stride;
+                            const uint8_t* rec = compact ? recs + at : recs + q * (size_t)stride;
+                            at += rec_bytes;
+                            if (sa_expand_record(rec, rec_bytes, row_bytes, r1.seq, r1.len, r2.seq, r2.len, a1.data(), a2.data(), &s) != SA_OK) {
                                 bad.store(1);
                                 break;
                             }
@@ -773,6 +794,7 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
         for (auto& w : workers) w.join();
         rc = err.load();
         rep->chunks_done = chunks_done.load();
+        rep->record_bytes = record_bytes.load();
         for (int d = 0; d < ndev; d++) {
             const Dev& D = devs[(size_t)d];
             t_wait += D.t_wait; t_format += D.t_format; t_write += D.t_write;

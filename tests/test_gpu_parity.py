@@ -967,3 +967,47 @@ def test_csv_driver_with_several_contexts_on_long_sequences(tmp_path, cooperativ
         rep = sa.run_csv(str(src), str(got), sa.TRIANGULAR, settings=st, pairs_per_submit=300)
         assert rep.chunks_done >= 4
         assert got.read_bytes() == want.read_bytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,lo,hi,seed", [(900, 1, 64, 61), (1500, 6, 50, 62), (150, 65, 400, 63)])
+def test_compact_records_are_the_strided_records_without_their_padding(n, lo, hi, seed):
+    """sa_set_compact_records: the packed stream a submission hands out holds, pair after pair, the first
+    sa_compact_record_size bytes of the strided record -- for whole schedules and for row ranges, both schedules."""
+    seqs, _ = synth.generate(n, lo, hi, seed)
+    al = sa.Aligner(max_seq_len=max(64, hi))
+    al.upload(seqs)
+    for schedule in (sa.TRIANGULAR, sa.ADJACENT):
+        rows = al.rows(schedule)
+        for r0, r1 in ((0, rows), (rows // 3, rows // 2), (rows - 1, rows)):
+            strided = al.align(schedule, r0, r1)
+            packed = al.align_compact(schedule, r0, r1)
+            assert packed.size == al.compact_bytes(schedule, r0, r1)
+            pairs = _tri_pairs(n, r0, r1) if schedule == sa.TRIANGULAR else [(k, k + 1) for k in range(r0, r1)]
+            base = al.compact_pair_offset(schedule, pairs[0][0], pairs[0][1])
+            step = max(1, len(pairs) // 3000)
+            for k in list(range(0, len(pairs), step)) + [len(pairs) - 1]:
+                i, j = pairs[k]
+                at = al.compact_pair_offset(schedule, i, j) - base
+                size = al.compact_record_size(j)
+                assert np.array_equal(packed[at : at + size], strided[k][:size]), (schedule, i, j)
+            # the last record ends where the stream ends; a packed record expands like a strided one
+            i, j = pairs[-1]
+            assert al.compact_pair_offset(schedule, i, j) - base + al.compact_record_size(j) == packed.size
+            at = al.compact_pair_offset(schedule, i, j) - base
+            assert al.expand(packed[at:], i, j)[:2] == al.expand(strided[-1], i, j)[:2]
+    al.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("compact", [1, 0])
+def test_host_formatter_reads_compact_and_strided_records(tmp_path, golden_dir, hashes, compact):
+    """The host formatting path of the CSV driver with records packed on the device (default) and with full-stride
+    records: the reference's all-vs-all file either way, and fewer bytes over PCIe with packing."""
+    out = tmp_path / "tri.csv"
+    rep = sa.run_csv(os.path.join(golden_dir, "avpdb.csv"), str(out), sa.TRIANGULAR, device_format=0, compact_records=compact,
+                     pairs_per_submit=50000)
+    assert sha256_file(out) == hashes["avpdb_triangular_out"]
+    assert rep.record_bytes == (542361 * 64 if not compact else rep.record_bytes)
+    if compact:
+        assert 542361 * 14 <= rep.record_bytes < 542361 * 40

@@ -386,3 +386,31 @@ def test_bench_refuses_more_gpus_than_there_are():
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64"], env=env, capture_output=True,
                          text=True, timeout=200)
     assert out.returncode != 0 and "--gpus 64" in out.stderr and out.stdout.strip() == ""
+
+
+def test_compact_record_arithmetic_without_a_device():
+    """Where a pair's packed record starts (sa_compact_pair_offset) and how long it is (sa_compact_record_size), against
+    the plain sums, for both schedules, peptides (8-byte header, a byte per row) and long sequences (16 + 2 per row)."""
+    import random
+    rng = random.Random(4)
+    for lo, hi, header, per_row in ((1, 64, 8, 1), (10, 300, 16, 2)):
+        seqs = ["".join(rng.choice("ACDEFGHIK") for _ in range(rng.randint(lo, hi))) for _ in range(41)]
+        al = sa.Aligner(device=sa.DEVICE_NONE, max_seq_len=hi)
+        al.upload(seqs)
+        n = len(seqs)
+        size = [(header + per_row * len(s) + 3) & ~3 for s in seqs]
+        assert [al.compact_record_size(j) for j in range(n)] == size
+        at = 0
+        for i in range(n - 1):
+            for j in range(i + 1, n):
+                assert al.compact_pair_offset(sa.TRIANGULAR, i, j) == at
+                at += size[j]
+        assert al.compact_bytes(sa.TRIANGULAR, 0, n - 1) == at
+        assert al.compact_bytes(sa.TRIANGULAR, 3, 7) == al.compact_pair_offset(sa.TRIANGULAR, 7, 8) - al.compact_pair_offset(sa.TRIANGULAR, 3, 4)
+        at = 0
+        for k in range(n - 1):
+            assert al.compact_pair_offset(sa.ADJACENT, k, k + 1) == at
+            at += size[k + 1]
+        assert al.compact_bytes(sa.ADJACENT, 0, n - 1) == at
+        assert al.compact_bytes(sa.ADJACENT, 5, 9) == sum(size[6:10])
+        al.close()
