@@ -159,6 +159,9 @@ typedef struct {
 int sa_set_text_layout(sa_ctx* ctx, const sa_text_layout* layout);
 int sa_upload_passthrough(sa_ctx* ctx, const char* bytes, const uint64_t* offs, uint64_t nseq);
 int sa_submit_text(sa_ctx* ctx, int schedule, uint64_t row_begin, uint64_t row_end);
+/* Optional, part of the set-up like sa_reserve_submission: the buffers of text submissions of up to `npairs` pairs and
+ * `text_bytes` bytes of text (device side of both slots, the two pinned buffers finished text is handed out in). */
+int sa_reserve_text(sa_ctx* ctx, uint64_t npairs, uint64_t text_bytes);
 int sa_next_text(sa_ctx* ctx, const char** text, uint64_t* nbytes, uint64_t* first_pair, uint64_t* npairs);
 
 /* ---- measurement: the same kernels with the records left in device memory.

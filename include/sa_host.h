@@ -39,7 +39,9 @@ typedef struct {
     uint32_t batch_size;              /* BATCH_SIZE: rows per batch; one GPU submission covers 4 batches unless pairs_per_submit is set */
     /* settings the reference does not have */
     int32_t schedule;                 /* SA_SCHEDULE_ADJACENT (the reference's) or SA_SCHEDULE_TRIANGULAR */
-    int32_t num_devices;              /* GPUs to use, chunks are dealt to them in turn */
+    int32_t num_devices;              /* GPUs to use at most, chunks are dealt to them in turn; a job too small to keep them busy uses
+                                         fewer (one per 30 ms of expected kernel time: a further GPU costs a copy of the sequences
+                                         and takes the same turns at the one output file) */
     int32_t devices[8];
     int32_t format_threads;           /* host threads that expand and format records; 0 = min(16, cores) */
     uint64_t pairs_per_submit;        /* 0 = batch_size * 4 (ADJACENT), batch_size * 64 (TRIANGULAR) */
@@ -50,6 +52,7 @@ typedef struct {
     int32_t cooperative;              /* SA_COOPERATIVE: sa_set_cooperative() of every context; default 0 (by pair count) */
     int32_t compact_records;          /* SA_COMPACT_RECORDS: 1 (default): records that travel to the host (host formatting, MODE_WRITE 0)
                                          are packed on the device first (sa_set_compact_records); 0: records of the full stride */
+    int32_t force_devices;            /* SA_FORCE_DEVICES: 1 = use all num_devices contexts whatever the size of the job (tests, measurements) */
 } sa_settings;
 
 typedef struct {
@@ -72,6 +75,7 @@ typedef struct {
     double device_format[8];
     double device_write[8];
     uint64_t record_bytes;            /* bytes of records copied from the devices to the host (0 when the GPUs wrote the text) */
+    int32_t devices_used;             /* of sa_settings.num_devices: as many as the job could feed (see sa_run_csv) */
 } sa_run_report;
 
 void sa_settings_default(sa_settings* st);

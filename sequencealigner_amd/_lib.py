@@ -72,6 +72,7 @@ class Settings(C.Structure):
         ("scoring_matrix_file", C.c_char * 4096),
         ("cooperative", C.c_int32),
         ("compact_records", C.c_int32),
+        ("force_devices", C.c_int32),
     ]
 
 
@@ -103,6 +104,7 @@ class RunReport(C.Structure):
         ("device_format", C.c_double * 8),
         ("device_write", C.c_double * 8),
         ("record_bytes", C.c_uint64),
+        ("devices_used", C.c_int32),
     ]
 
 
@@ -145,6 +147,7 @@ SIGNATURES = {
     "sa_compact_bytes": (C.c_uint64, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64]),
     "sa_set_text_layout": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sa_upload_passthrough": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.c_uint64]),
+    "sa_reserve_text": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64]),
     "sa_submit_text": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64]),
     "sa_next_text": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "sa_expand_record": (

@@ -1272,6 +1272,22 @@ int sa_reserve_submission(sa_ctx* c, uint64_t npairs, uint32_t longest_sequence)
     return SA_OK;
 }
 
+int sa_reserve_text(sa_ctx* c, uint64_t npairs, uint64_t text_bytes) {
+    if (!c || npairs == 0) return SA_ERR_ARG;
+    if (c->device == SA_DEVICE_NONE || c->inflight) return SA_ERR_STATE;
+    SA_HIP_TRY(hipSetDevice(c->device));
+    int rc;
+    for (Work& w : c->slots) {
+        if ((rc = w.lens.reserve(npairs * 4)) || (rc = w.offs.reserve(npairs * 8)) || (rc = w.total.reserve(8)) ||
+            (rc = w.scan_tmp.reserve(std::max<size_t>(16, sa_format_scan_bytes(npairs)))) || (rc = w.text.reserve(text_bytes)) ||
+            (rc = w.host_total.reserve(8)))
+            return rc;
+    }
+    for (PinBuf& b : c->text_ring)
+        if ((rc = b.reserve(text_bytes))) return rc;
+    return SA_OK;
+}
+
 int sa_set_compact_records(sa_ctx* c, int enable) {
     if (!c) return SA_ERR_ARG;
     if (c->inflight) return SA_ERR_STATE;

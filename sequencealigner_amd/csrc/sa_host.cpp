@@ -347,6 +347,7 @@ int sa_settings_load(sa_settings* st, const char* path) {
         else if (k == "SA_NUM_DEVICES") { if (num(x)) st->num_devices = (int32_t)x; }
         else if (k == "SA_COOPERATIVE") { if (num(x)) st->cooperative = (int32_t)x; }
         else if (k == "SA_COMPACT_RECORDS") { if (num(x)) st->compact_records = (int32_t)x; }
+        else if (k == "SA_FORCE_DEVICES") { if (num(x)) st->force_devices = (int32_t)x; }
         else if (k == "SA_SCORING_MATRIX") { if (!parse_c_string(v, st->scoring_matrix_file, sizeof(st->scoring_matrix_file))) st->scoring_matrix_file[0] = 0; }
     }
     fclose(f);
@@ -460,6 +461,14 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
             const uint64_t pairs0 = std::max<uint64_t>(1, std::min<uint64_t>(cap0, (256ull << 20) / per_pair));
             rc = sa_reserve_submission(ctx[(size_t)d], pairs0, max_len);
         }
+        if (rc == SA_OK && text_mode) {
+            // text submissions: the same cap as below, the worst-case row of a sequence of MAX_SEQ_LEN - 1 residues
+            uint64_t cap0 = st->pairs_per_submit ? st->pairs_per_submit
+                                                 : (uint64_t)st->batch_size * (st->schedule == SA_SCHEDULE_TRIANGULAR ? 64 : 4);
+            cap0 = std::max<uint64_t>(1, std::min<uint64_t>(cap0, std::max<uint64_t>(1024, (1ull << 30) / (6ull * st->max_seq_len + 600))));
+            const uint64_t text0 = std::min<uint64_t>(cap0 * (6ull * max_len + 256), 256ull << 20);
+            rc = sa_reserve_text(ctx[(size_t)d], cap0, text0);
+        }
         if (rc) { cleanup(); return fail(rc); }
     }
 
@@ -521,6 +530,19 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
     if (n >= 2) {
         const double tu0 = now_s();
         const int schedule = st->schedule;
+        // How many of the contexts this job can keep busy: one per 30 ms of expected kernel time (a pair-per-lane
+        // kernel does about 2e12 cells a second on adjacent pairs, 8e12 on all-vs-all).  A further context costs a copy
+        // of the sequences and its share of the host's turns at the output file: the 4 001 280-row data set (2.2e9
+        // cells, a few milliseconds of kernel time) took 0.16 s on one context and 0.21 s on three.
+        int ndev = st->num_devices;
+        {
+            double cells = 0;
+            if (schedule == SA_SCHEDULE_ADJACENT) for (uint64_t s = 0; s + 1 < n; s++) cells += (double)lens[s] * lens[s + 1];
+            else { double suffix = 0; for (uint64_t s = n; s-- > 0;) { cells += (double)lens[s] * suffix; suffix += lens[s]; } }
+            const double est_ms = cells / (schedule == SA_SCHEDULE_ADJACENT ? 2e12 : 8e12) * 1e3;
+            if (!st->force_devices) ndev = std::max(1, std::min(ndev, (int)(est_ms / 30.0)));
+        }
+        rep->devices_used = ndev;
         // The first context takes the sequences from the host (validation, slots, length tables; for TRIANGULAR the
         // bucket order and cursor table; for rows written on the GPU the layout and the pass-through text); the
         // others clone it device to device, all at once.

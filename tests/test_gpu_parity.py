@@ -358,6 +358,23 @@ def test_full_size_protein_set_sampled_against_oracle():
     d0 = al.digest_resident(0, total)
     al.run_resident()
     assert al.digest_resident(0, total) == d0
+    # Every one of the 5.0e7 records against the 32-bit pair-per-lane kernel (no packed cells, no checkpoints, whole
+    # direction matrix kept): digest per block of rows, the two launches one after the other since each leaves 100 GB
+    step = total // 50 + 1
+    blocks = [(first, min(step, total - first)) for first in range(0, total, step)]
+    packed = [al.digest_resident(first, cnt) for first, cnt in blocks]
+    probe = al.fetch_resident(total // 2, 2000)
+    al.close()
+    ref = sa.Aligner(max_seq_len=1000)
+    ref.upload(seqs)
+    ref.set_pairing(False)
+    ref.prepare_resident(sa.TRIANGULAR, 0, rows)
+    ref.run_resident()
+    assert ref.last_kernel().startswith("sa_long_kernel")
+    for (first, cnt), d in zip(blocks, packed):
+        assert ref.digest_resident(first, cnt) == d, first
+    assert np.array_equal(ref.fetch_resident(total // 2, 2000), probe)
+    ref.close()
 
 
 @pytest.mark.gpu
@@ -544,10 +561,11 @@ def test_csv_driver_deals_chunks_to_several_contexts(tmp_path, schedule):
     oracle_lib.run_file(str(src), str(want), schedule, threads=8)
     st = sa.default_settings()
     st.num_devices = 3
+    st.force_devices = 1          # a job this small would otherwise run on one context
     for k in range(3):
         st.devices[k] = 0
     rep = sa.run_csv(str(src), str(got), schedule, settings=st, pairs_per_submit=7000)
-    assert rep.chunks_done >= 6
+    assert rep.chunks_done >= 6 and rep.devices_used == 3
     assert got.read_bytes() == want.read_bytes()
     # every context had its own submit and drain thread, and reported what they spent
     assert all(rep.device_submit[k] > 0 and rep.device_wait[k] > 0 for k in range(3))
@@ -555,6 +573,11 @@ def test_csv_driver_deals_chunks_to_several_contexts(tmp_path, schedule):
     # the same through the host formatter
     st.device_format = 0
     sa.run_csv(str(src), str(got), schedule, settings=st, pairs_per_submit=7000, format_threads=5)
+    assert got.read_bytes() == want.read_bytes()
+    # left to itself the driver gives a job of a few milliseconds one context, whatever number it may use
+    st.force_devices = 0
+    rep = sa.run_csv(str(src), str(got), schedule, settings=st, pairs_per_submit=7000)
+    assert rep.devices_used == 1 and rep.device_submit[1] == 0
     assert got.read_bytes() == want.read_bytes()
 
 
@@ -960,6 +983,7 @@ def test_csv_driver_with_several_contexts_on_long_sequences(tmp_path, cooperativ
     for device_format in (1, 0):
         st = sa.default_settings()
         st.num_devices = 2
+        st.force_devices = 1
         st.devices[0] = st.devices[1] = 0
         st.max_seq_len = 1024
         st.cooperative = cooperative

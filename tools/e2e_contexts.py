@@ -12,6 +12,7 @@ for ndev, write in ((1, 1), (2, 1), (3, 1), (4, 1), (1, 0), (2, 0), (3, 0), (4, 
     for rep in range(3):
         st = sa.default_settings()
         st.num_devices = ndev
+        st.force_devices = 1
         for k in range(ndev):
             st.devices[k] = 0
         rep_ = sa.run_csv(path, out, sa.ADJACENT, settings=st)
