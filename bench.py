@@ -20,7 +20,8 @@ Rank 0 prints one JSON line.  Besides the contract's fields it carries
                 bounded sample of the bench workload, both on this box's host cores
   extra         the same workload on the 32-bit kernel, through PCIe to pinned host memory
                 (the reference's "without write"), the 4 001 280-row data set end to end into
-                a CSV file (its "with write"), and the protein workloads
+                a CSV file (its "with write") and resident on the ADJACENT kernel, the reference's
+                own 1 042-sequence data set all-vs-all end to end, and the protein workloads
 """
 import argparse
 import hashlib
@@ -46,7 +47,13 @@ HBM_PEAK_GBS = 8000.0
 # Per-launch counter totals of the kernels, from separate rocprofv3 --pmc passes of this same command
 # (tools/pmc_pass.sh; FETCH_SIZE doubled as gfx950 requires, WRITE_SIZE as read).  The passes' summaries
 # are kept under profiles/; this file is refreshed whenever a kernel changes.
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc.json")
+MIX_PEAK_FILE = "profiles/r02_valu_cell_block_rates.txt"      # tools/valu_peak.hip: the packed column-pair block back to back
+# nominal: 256 CUs x 256 B per clock x 2.4 GHz (ds_read_b64; ds_read2_b64 and b128 run at half of it, measured on the
+# values-only row of tools/row_bench.hip, profiles/r03_row_bench.txt)
+LDS_PEAK_FILE = "nominal 256 CUs x 256 B/clk x 2.4 GHz; ds_read_b64 rows with and without their LDS reads in profiles/r03_row_bench.txt"
+AVPDB_TRIANGULAR_SHA256 = "3eb3798aa4d2adff6aabe7bf69f06ef1425d2c25005b456f2a6440eff47e1e08"   # the reference's own output
+AVPDB_CELLS = 252634121
 MEGA_SHA256 = "667f3524a9ba31243de55c075165b336010ffeaf76600b39540b54f5dd085f18"   # the reference's own output, 500 832 027 bytes
 MEGA_CELLS = 2214981084
 
@@ -58,7 +65,22 @@ WORKLOADS = {
     "peptides4k": (4000, 6, 50, 1, "synthetic 4k peptides len 6-50 seed 1, all-vs-all"),
     "proteins10k": (10000, 300, 1000, 2, "synthetic 10k proteins len 300-1000 seed 2, all-vs-all (BASELINE.json configs[4])"),
     "proteins2k": (2000, 300, 1000, 2, "first 2000 of the synthetic proteins len 300-1000 seed 2, all-vs-all"),
+    # the reference's enlarged data set (BASELINE.json configs[3]): no generator, read from the golden avpdb.csv
+    "mega": (4001280, 2, 46, None, "mega data set: avpdb.csv forwards + backwards x 1920, 4 001 279 adjacent pairs"),
 }
+
+
+def workload_sequences(sa, synth, name):
+    """(sequences, labels, schedule) of a workload."""
+    n, lo, hi, seed, _ = WORKLOADS[name]
+    if name == "mega":
+        with open(os.path.join(ROOT, "tests", "golden", "avpdb.csv"), "rb") as f:
+            rows = [line.split(b",") for line in f.read().split(b"\n")[1:] if line]
+        seqs = [r[0] for r in rows]
+        labels = [int(r[1]) for r in rows]
+        return (seqs + seqs[::-1]) * 1920, (labels + labels[::-1]) * 1920, sa.ADJACENT
+    seqs, labels = synth.generate(n, lo, hi, seed)
+    return seqs, labels, sa.TRIANGULAR
 
 
 def visible_gpus():
@@ -203,26 +225,35 @@ def cpu_baseline(sa, synth, seqs, labels, sample_n, mega_path):
                           "pairs_per_s": round(st.pairs / st.seconds, 1), "seconds": round(st.seconds, 3),
                           "sample": f"first {sample_n} of the {len(seqs)} sequences, all-vs-all ({st.pairs} pairs, {st.cells} cells), "
                                     f"score + traceback, no CSV write, {threads} threads"})
+    # BASELINE.json configs[0]: the reference's own CPU-runnable case, avpdb.csv all-vs-all, on the restatement
+    threads = min(cores, 16)
+    st = oracle_lib.run_file(os.path.join(ROOT, "tests", "golden", "avpdb.csv"), None, 1, threads=threads)
+    avpdb = {"value": round(st.cells / st.seconds / 1e9, 3), "unit": "GCUPS", "cores": threads, "kind": "port",
+             "pairs_per_s": round(st.pairs / st.seconds, 1), "seconds": round(st.seconds, 4), "cells": st.cells,
+             "sample": f"avpdb.csv all-vs-all ({st.pairs} pairs, {st.cells} cells), score + traceback, no CSV write, {threads} threads"}
     if out:
         out["port"] = ports
     else:
         out = dict(ports[0])
         out["port"] = ports[1:]
+    out["avpdb_all_pairs"] = avpdb
     out["host_cores_available"] = cores
     return out
 
 
-def resident_measurement(sa, synth, name, device, launches=2, pairing=True):
+def resident_measurement(sa, synth, name, device, launches=2, pairing=True, checkpoint_rows=None):
     """A workload measured with the records left in HBM (not part of `value`)."""
     n, lo, hi, seed, desc = WORKLOADS[name]
-    seqs, _ = synth.generate(n, lo, hi, seed)
+    seqs, _, schedule = workload_sequences(sa, synth, name)
     al = sa.Aligner(device=device, max_seq_len=max(64, hi))
     al.set_pairing(pairing)
+    if checkpoint_rows is not None:
+        al.set_long_checkpoint_rows(checkpoint_rows)
     al.upload(seqs)
-    rows = al.rows(sa.TRIANGULAR)
-    cells = al.cell_count(sa.TRIANGULAR, 0, rows)
-    pairs = al.pair_count(sa.TRIANGULAR, 0, rows)
-    al.prepare_resident(sa.TRIANGULAR, 0, rows)
+    rows = al.rows(schedule)
+    cells = al.cell_count(schedule, 0, rows)
+    pairs = al.pair_count(schedule, 0, rows)
+    al.prepare_resident(schedule, 0, rows)
     al.run_resident()
     ms = [al.run_resident() for _ in range(launches)]
     kernel = al.last_kernel()
@@ -231,6 +262,8 @@ def resident_measurement(sa, synth, name, device, launches=2, pairing=True):
     out = {"workload": desc, "kernel": kernel, "pairs": pairs, "cells": cells, "kernel_ms": round(k_ms, 3),
            "gcups": round(cells / k_ms / 1e6, 1), "pairs_per_s": round(pairs / k_ms * 1e3, 1),
            "roofline_frac": round(cells * OPS_PER_CELL / (k_ms * 1e-3) / 1e12 / PEAK_TIOPS, 4)}
+    if "pair" in kernel or "ckpt" in kernel:
+        out["roofline_frac_packed16"] = round(out["roofline_frac"] / 2, 4)
     rec = pmc_record(kernel, name)
     if rec:
         out["counters"] = counter_rates(rec, k_ms)
@@ -277,10 +310,11 @@ def counter_rates(rec, k_ms):
                         # the packed kernels' column-pair block issued back to back with no memory access, four waves per
                         # SIMD (tools/valu_peak.hip, profiles/r02_valu_cell_block_rates.txt): the chip lowers its clock to
                         # 1.94 GHz under that stream, so this, not the 2.4 GHz line, is what the instruction mix can reach
-                        "mix_peak": MIX_PEAK_TLANE, "mix_frac": round(lane / sec / 1e12 / MIX_PEAK_TLANE, 4)}
+                        "mix_peak": MIX_PEAK_TLANE, "mix_peak_from": MIX_PEAK_FILE,
+                        "mix_frac": round(lane / sec / 1e12 / MIX_PEAK_TLANE, 4)}
     if rec.get("lds_bytes"):
         out["lds"] = {"bytes_per_launch": rec["lds_bytes"], "achieved": round(rec["lds_bytes"] / sec / 1e12, 2),
-                      "peak": LDS_PEAK_TBS, "unit": "TB/s", "frac": round(rec["lds_bytes"] / sec / 1e12 / LDS_PEAK_TBS, 4),
+                      "peak": LDS_PEAK_TBS, "peak_from": LDS_PEAK_FILE, "unit": "TB/s", "frac": round(rec["lds_bytes"] / sec / 1e12 / LDS_PEAK_TBS, 4),
                       "bank_conflict_share": rec.get("lds_bank_conflict_share")}
     if rec.get("fetch_bytes") is not None and rec.get("write_bytes") is not None:
         t = rec["fetch_bytes"] + rec["write_bytes"]
@@ -303,6 +337,24 @@ def d2h_measurement(sa, csv_path, cells):
                                     "gcups": round(cells / full.seconds / 1e9, 1)},
             "seconds_ingest": round(rep.seconds_ingest, 4), "seconds_upload": round(rep.seconds_upload, 4),
             "seconds_gpu_wait": round(rep.seconds_gpu_wait, 4)}
+
+
+def e2e_avpdb(sa, out_dir, device):
+    """BASELINE.json configs[1]: the reference's own data set (1 042 sequences), all-vs-all, CSV in -> CSV out, checked
+    against the sha256 of the reference's output.  A job of half a million pairs: set-up and the write are most of it."""
+    src = os.path.join(ROOT, "tests", "golden", "avpdb.csv")
+    dst = os.path.join(out_dir, "avpdb_triangular.csv")
+    st = sa.default_settings()
+    st.num_devices = 1
+    st.devices[0] = device
+    best = min((sa.run_csv(src, dst, sa.TRIANGULAR, settings=st) for _ in range(3)), key=lambda r: r.seconds)
+    ok = sha256_file(dst) == AVPDB_TRIANGULAR_SHA256
+    os.unlink(dst)
+    nowrite = min((sa.run_csv(src, None, sa.TRIANGULAR, settings=st) for _ in range(3)), key=lambda r: r.seconds)
+    return {"what": "avpdb.csv all-vs-all (542 361 pairs) CSV in -> CSV out, set-up excluded as in the reference's timing",
+            "seconds": round(best.seconds, 4), "pairs_per_s": round(best.pairs / best.seconds, 1),
+            "gcups": round(best.cells / best.seconds / 1e9, 2), "cells": best.cells, "bytes_written": best.bytes_written,
+            "sha256_ok": ok, "without_write": {"seconds": round(nowrite.seconds, 4), "gcups": round(nowrite.cells / nowrite.seconds / 1e9, 2)}}
 
 
 def sha256_file(path):
@@ -427,13 +479,13 @@ def main():
             torch.cuda.synchronize()
 
     n, lo, hi, seed, desc = WORKLOADS[args.workload]
-    seqs, labels = synth.generate(n, lo, hi, seed)
+    seqs, labels, schedule = workload_sequences(sa, synth, args.workload)
     al = sa.Aligner(device=local_rank, max_seq_len=max(64, hi))   # raises if the HIP library or the device is missing
     al.upload(seqs)
-    r0, r1 = shard_for_rank(al, sa.TRIANGULAR, rank, world)
-    my_pairs = al.pair_count(sa.TRIANGULAR, r0, r1)
-    my_cells = al.cell_count(sa.TRIANGULAR, r0, r1)
-    al.prepare_resident(sa.TRIANGULAR, r0, r1)
+    r0, r1 = shard_for_rank(al, schedule, rank, world)
+    my_pairs = al.pair_count(schedule, r0, r1)
+    my_cells = al.cell_count(schedule, r0, r1)
+    al.prepare_resident(schedule, r0, r1)
 
     for _ in range(args.warmup):
         al.run_resident()
@@ -456,7 +508,7 @@ def main():
         rec = pmc_record(kernel, args.workload) if world == 1 and k_ms > 0 else None
         rates = counter_rates(rec, k_ms) if rec else {}
         mem = rates.get("memory_side")
-        packed = "pair" in kernel
+        packed = "pair" in kernel or "ckpt" in kernel
         out = {
             "metric": "GCUPS, all-vs-all Needleman-Wunsch score+traceback (aligned pairs/s alongside)",
             "value": round(total_cells * args.steps / elapsed / 1e9, 2),
@@ -477,15 +529,28 @@ def main():
                 "sequences": n,
                 "pairs": int(total_pairs),
                 "cells": int(total_cells),
-                "schedule": "triangular, contiguous row ranges of equal cell count per GPU",
+                "schedule": ("triangular" if schedule == sa.TRIANGULAR else "adjacent") + ", contiguous row ranges of equal cell count per GPU",
                 "results": f"{al.stride}-byte record per pair (score, matches, gaps, traceback) left in HBM",
             },
+            "notes": [
+                "value is the kernels' throughput with the records left in HBM; what a caller receives over PCIe is extra.d2h",
+                "BASELINE.json configs[3] (extra.e2e_mega: 4 001 279 adjacent pairs, CSV in -> CSV out) is host-bound: its kernel "
+                "takes about 2 ms (extra.adjacent_kernel) of about 160 ms; ingest, upload and the 500 MB write are the rest, so "
+                "further GPUs do not make it faster and the CSV driver gives such a job one context",
+                "N > 1: every rank aligns its own row range of the triangle, no collective on the data path; two ranks have "
+                "been run on one card (tests/test_gpu_cli.py), no 2-, 4- or 8-GPU figure has been measured by this repository",
+            ],
             "roofline": {
-                "bound": "valu_int32",
+                "bound": "valu",
+                "bound_detail": "vector ALU issue: neither HBM nor MFMA bounds this path.  The packed kernels' recurrence is one v_add_u32 "
+                                "and one v_pk_maximum3_f16 on 16-bit integer patterns per two cells (plus the tag fields); the 32-bit "
+                                "kernels use v_add_u32 / v_max3_i32.  peak = the plain INT32 lane rate; a packed instruction does two "
+                                "cells, so frac_packed16 (= achieved / (2 x peak)) is the fraction to read for the packed kernels",
                 "achieved": round(achieved, 3),
                 "peak": round(PEAK_TIOPS, 2),
                 "unit": "TIOP/s",
                 "frac": round(achieved / PEAK_TIOPS, 4),
+                "frac_packed16": round(achieved / PEAK_TIOPS / 2, 4) if packed else None,
                 "traffic": mem["bytes_per_launch"] if mem else None,
                 "issue_frac": rates.get("issue", {}).get("frac"),
                 "issue": rates.get("issue"),
@@ -520,8 +585,11 @@ def main():
                     mega_path = os.path.join(tmp.name, "mega.csv")
                     synth.make_mega(os.path.join(ROOT, "tests", "golden", "avpdb.csv"), mega_path)
                     extra["e2e_mega"] = e2e_mega(sa, mega_path, tmp.name, local_rank)
+                    extra["adjacent_kernel"] = resident_measurement(sa, synth, "mega", local_rank, launches=5)
+                    extra["e2e_avpdb_triangular"] = e2e_avpdb(sa, tmp.name, local_rank)
                     extra["few_long_pairs"] = few_pairs_measurement(sa, synth, local_rank)
                     extra["proteins2k"] = resident_measurement(sa, synth, "proteins2k", local_rank)
+                    extra["proteins2k_direction_rows_kernel"] = resident_measurement(sa, synth, "proteins2k", local_rank, checkpoint_rows=0)
                     extra["proteins10k"] = resident_measurement(sa, synth, "proteins10k", local_rank, launches=1)
                 out["extra"] = extra
                 if args.cpu_sample > 0:

@@ -205,6 +205,12 @@ int sa_set_long_checkpoint_rows(sa_ctx* ctx, uint32_t rows);
  * chooses by the pair count of the submission, 1 = for every submission of long sequences of up to 4096 pairs per CU
  * (beyond that the per-pair work list would not be worth its memory), -1 = never.  Same records either way. */
 int sa_set_cooperative(sa_ctx* ctx, int mode);
+/* Waves per pair in that kernel.  0 (default): from the pair count -- with fewer pairs than the chip has wave slots
+ * (16 per CU) a pair gets a workgroup of 2, 4, 8 or 16 waves, which take its 64-column strips in turn and hand a
+ * strip's last column to the wave on their right through LDS, 64 rows at a time, while both are being swept; 64 pairs
+ * of 4096 residues then keep 1024 waves busy, not 64.  1, 2, 4, 8, 16: that many, whatever the count (measurements).
+ * The reference has no counterpart: it aligns a pair on one thread (include/seqalign.h:13-113).  Same records. */
+int sa_set_cooperative_waves(sa_ctx* ctx, int waves);
 
 /* name of the fill + traceback kernel the context's most recent launch ran ("" before the first): the library picks
  * between packed 16-bit and 32-bit cells, peptide and strip kernels from the table, the lengths and the row range */

@@ -140,6 +140,7 @@ SIGNATURES = {
     "sa_last_kernel": (C.c_char_p, [C.c_void_p]),
     "sa_set_pairing": (C.c_int, [C.c_void_p, C.c_int]),
     "sa_set_cooperative": (C.c_int, [C.c_void_p, C.c_int]),
+    "sa_set_cooperative_waves": (C.c_int, [C.c_void_p, C.c_int]),
     "sa_set_long_checkpoint_rows": (C.c_int, [C.c_void_p, C.c_uint32]),
     "sa_set_compact_records": (C.c_int, [C.c_void_p, C.c_int]),
     "sa_compact_record_size": (C.c_uint32, [C.c_void_p, C.c_uint64]),
@@ -321,6 +322,10 @@ class Aligner:
     def set_cooperative(self, mode):
         """Wave-per-pair kernel for long sequences: 0 = by pair count (default), 1 = always, -1 = never."""
         _check(self._lib.sa_set_cooperative(self._ctx, mode))
+
+    def set_cooperative_waves(self, waves):
+        """Waves per pair in the wave-per-pair kernel: 0 = from the pair count (default), else 1, 2, 4, 8 or 16."""
+        _check(self._lib.sa_set_cooperative_waves(self._ctx, waves))
 
     def set_long_checkpoint_rows(self, rows):
         """Packed long-sequence kernel: 64 (default) or 32 rows between checkpoints, 0 = whole direction matrix."""

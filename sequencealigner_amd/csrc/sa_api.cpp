@@ -29,6 +29,7 @@ extern "C" hipError_t sa_launch_format(const SaFormatParams* F, void* scan_tmp, 
 extern "C" void sa_launch_long_pair(const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream);
 extern "C" void sa_launch_long_ckpt(int ck_rows, const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream);
 extern "C" void sa_launch_coop(const SaPepParams* p, unsigned grid, hipStream_t stream);
+extern "C" void sa_launch_coop_wg(int waves, const SaPepParams* p, unsigned grid, hipStream_t stream);
 extern "C" void sa_launch_long(int mode, const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream);
 extern "C" void sa_launch_compact(int schedule, const uint8_t* out, uint8_t* packed, const uint64_t* cp, const uint64_t* cq,
                                   uint64_t nseq, uint64_t r0, uint64_t r1, uint32_t stride, hipStream_t stream);
@@ -133,6 +134,7 @@ struct sa_ctx {
     int64_t sprime_min = 0, sprime_max = 0;   // range of S' = S - 2*gap over the table: decides whether packed cells fit
     uint32_t bucket_width = 1;
     int coop_mode = 0;                 // wave-per-pair kernel for long sequences: 0 = when a submission has few pairs, 1 always, -1 never
+    int coop_waves = 0;                // waves per pair in that kernel: 0 = from the number of pairs, else 1, 2, 4, 8 or 16
     bool compact = false;              // sa_set_compact_records: submissions hand out packed records
     std::vector<uint64_t> cp, cq;      // prefix arrays of the packed record sizes (sa_compact.hip), built with the upload
     DevBuf d_cp, d_cq;
@@ -423,6 +425,18 @@ bool use_coop(const sa_ctx* c, uint64_t npairs) {
     if (c->coop_mode > 0) return npairs <= 4096ull * (uint64_t)c->ncu;
     return npairs <= 384ull * (uint64_t)c->ncu;
 }
+// Waves per pair: with fewer pairs than wave slots (16 per CU) a pair gets a workgroup of several waves, which share
+// its strips (sa_coop_wg_kernel): the largest power of two with which (nearly) every pair still has a workgroup in
+// flight.  Measured (tools/coop_waves_sweep.py, ms at 1 / 2 / 4 / 8 / 16 waves): 64 pairs of 2000-4096 residues 9.9 /
+// 5.9 / 3.4 / 2.8 / 2.7, 512 such pairs 10.4 / 7.9 / 3.6 / 3.6 / 3.9, 1024: 10.6 / 8.0 / 5.3 / 5.5 / 7.4; proteins of
+// 300-1000 residues, 496 pairs 0.76 / 0.55 / 0.40 / 0.37 / 0.54, 1035 pairs 0.82 / 0.63 / 0.47 / 0.64 / 1.09, 4095 pairs
+// 1.25 / 1.15 / 1.33 / 2.19 / 4.01.
+int coop_waves_for(const sa_ctx* c, uint64_t npairs) {
+    if (c->coop_waves) return c->coop_waves;
+    int w = 1;
+    while (w < 16 && npairs * (uint64_t)(2 * w) <= 20ull * (uint64_t)c->ncu) w *= 2;
+    return w;
+}
 // its scratch per workgroup, KiB: direction blocks (strips x 16-step blocks x 256 B), two border columns, row notes
 uint32_t coop_kib_per_wg(const sa_ctx* c) {
     const uint64_t steps_cap = c->lslot + 128;
@@ -534,13 +548,20 @@ int launch_work(sa_ctx* c, Work& w, bool timed) {
     P.bcol = (int32_t*)c->d_bcol.p;
     const bool tri = w.schedule == SA_SCHEDULE_TRIANGULAR;
     if (w.coop) {
-        const uint32_t cgrid = (uint32_t)std::min<uint64_t>(w.nitems, (uint64_t)c->ncu * 16);
+        const int waves = coop_waves_for(c, w.nitems);
+        const uint32_t cgrid = (uint32_t)std::min<uint64_t>(w.nitems, (uint64_t)c->ncu * 16 / waves);
         const uint32_t kib = coop_kib_per_wg(c);
         if ((rc = c->d_coop.reserve((size_t)cgrid * kib * 1024))) return rc;
         P.spill = (uint32_t*)c->d_coop.p;
         P.spill_rows = kib;
-        sa_launch_coop(&P, cgrid, c->compute);
-        c->last_kernel = "sa_coop_kernel";
+        if (waves == 1) {
+            sa_launch_coop(&P, cgrid, c->compute);
+            c->last_kernel = "sa_coop_kernel";
+        } else {
+            sa_launch_coop_wg(waves, &P, cgrid, c->compute);
+            c->last_kernel = waves == 2 ? "sa_coop_wg_kernel<2>" : waves == 4 ? "sa_coop_wg_kernel<4>"
+                           : waves == 8 ? "sa_coop_wg_kernel<8>" : "sa_coop_wg_kernel<16>";
+        }
     } else if (ckpt) {
         sa_launch_long_ckpt((int)c->ckpt_rows, &P, grid, SA_LDS_PROF_BYTES + 64 + 2 * c->lslot, c->compute);
         c->last_kernel = c->ckpt_rows == 64 ? "sa_long_ckpt_kernel<64, 64>" : "sa_long_ckpt_kernel<32, 64>";
@@ -1251,6 +1272,14 @@ int sa_set_cooperative(sa_ctx* c, int mode) {
     if (!c || mode < -1 || mode > 1) return SA_ERR_ARG;
     if (c->inflight) return SA_ERR_STATE;
     c->coop_mode = mode;
+    c->resident_ready = false;
+    return SA_OK;
+}
+
+int sa_set_cooperative_waves(sa_ctx* c, int waves) {
+    if (!c || (waves != 0 && waves != 1 && waves != 2 && waves != 4 && waves != 8 && waves != 16)) return SA_ERR_ARG;
+    if (c->inflight) return SA_ERR_STATE;
+    c->coop_waves = waves;
     c->resident_ready = false;
     return SA_OK;
 }

@@ -53,6 +53,34 @@ __device__ __forceinline__ uint32_t sa_writelane(int value, int lane_index, uint
     return dst;
 }
 
+// One step of the sweep, for both kernels of this file (the names are the kernels' locals); TL = t mod 64 is a literal,
+// so that lane indices are immediates.
+#define SA_COOP_STEP(TL)                                                                                              \
+    {                                                                                                                 \
+        const int T = Tq[0];                                                                                          \
+        _Pragma("unroll") for (int k = 0; k + 1 < SA_COOP_AHEAD; k++) Tq[k] = Tq[k + 1];                              \
+        Tq[SA_COOP_AHEAD - 1] = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(tab) + a32 + b * 4);  \
+        /* the residues of the step after: from the lane on the left, lane 0 takes the next residue */               \
+        b = sa_wave_shr1(__builtin_amdgcn_readlane(resin, (TL)), b);                                                  \
+        const int m = left_prev + T;                                                                                  \
+        const int h = max3i(m, up, left);                                                                             \
+        acc = __builtin_amdgcn_alignbit((uint32_t)h, acc, 2);                                                         \
+        const int zl = h & ~3;                                                                                        \
+        up = zl | 1;                                                                                                  \
+        left_prev = left;                                                                                             \
+        /* the strip's last column, row t - 63, for the next strip */                                                 \
+        const int last = __builtin_amdgcn_readlane(zl, 63);                                                           \
+        SA_WRITELANE_CONST(colbuf, last, (TL));                                                                       \
+        /* next step's LEFT comes from the lane on the left; lane 0 takes the border column's next row */             \
+        left = sa_wave_shr1(__builtin_amdgcn_readlane(colin, (TL)), zl);                                              \
+    }
+#define SA_COOP_BLOCK(B)                                                                                              \
+    SA_COOP_STEP(16 * (B) + 0) SA_COOP_STEP(16 * (B) + 1) SA_COOP_STEP(16 * (B) + 2) SA_COOP_STEP(16 * (B) + 3)       \
+    SA_COOP_STEP(16 * (B) + 4) SA_COOP_STEP(16 * (B) + 5) SA_COOP_STEP(16 * (B) + 6) SA_COOP_STEP(16 * (B) + 7)       \
+    SA_COOP_STEP(16 * (B) + 8) SA_COOP_STEP(16 * (B) + 9) SA_COOP_STEP(16 * (B) + 10) SA_COOP_STEP(16 * (B) + 11)     \
+    SA_COOP_STEP(16 * (B) + 12) SA_COOP_STEP(16 * (B) + 13) SA_COOP_STEP(16 * (B) + 14) SA_COOP_STEP(16 * (B) + 15)   \
+    dirs[((size_t)s * blocks_cap + 4 * sb + (B)) * 64 + lane] = acc;
+
 __global__ void __launch_bounds__(64, 4) sa_coop_kernel(const SaPepParams P) {
     __shared__ int32_t tab[21 * 32];        // tab[a * 32 + b] = 4 S'[a][b] + 3; b = SA_COOP_NEG_CODE: far below any score
     const int lane = threadIdx.x;
@@ -123,35 +151,7 @@ __global__ void __launch_bounds__(64, 4) sa_coop_kernel(const SaPepParams P) {
                 // below the matrix the border is 0 (what the buffer holds there is stale, and a LEFT operand above the
                 // frozen column value would thaw it)
                 const int colin = (first_strip || rown >= len2) ? 0 : bin[rown];
-                // One step; TL = t mod 64 is a literal, so that lane indices are immediates.
-#define SA_COOP_STEP(TL)                                                                                              \
-    {                                                                                                                 \
-        const int T = Tq[0];                                                                                          \
-        _Pragma("unroll") for (int k = 0; k + 1 < SA_COOP_AHEAD; k++) Tq[k] = Tq[k + 1];                              \
-        Tq[SA_COOP_AHEAD - 1] = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(tab) + a32 + b * 4);  \
-        /* the residues of the step after: from the lane on the left, lane 0 takes the next residue */               \
-        b = sa_wave_shr1(__builtin_amdgcn_readlane(resin, (TL)), b);                                                  \
-        const int m = left_prev + T;                                                                                  \
-        const int h = max3i(m, up, left);                                                                             \
-        acc = __builtin_amdgcn_alignbit((uint32_t)h, acc, 2);                                                         \
-        const int zl = h & ~3;                                                                                        \
-        up = zl | 1;                                                                                                  \
-        left_prev = left;                                                                                             \
-        /* the strip's last column, row t - 63, for the next strip */                                                 \
-        const int last = __builtin_amdgcn_readlane(zl, 63);                                                           \
-        SA_WRITELANE_CONST(colbuf, last, (TL));                                                                       \
-        /* next step's LEFT comes from the lane on the left; lane 0 takes the border column's next row */             \
-        left = sa_wave_shr1(__builtin_amdgcn_readlane(colin, (TL)), zl);                                              \
-    }
-#define SA_COOP_BLOCK(B)                                                                                              \
-    SA_COOP_STEP(16 * (B) + 0) SA_COOP_STEP(16 * (B) + 1) SA_COOP_STEP(16 * (B) + 2) SA_COOP_STEP(16 * (B) + 3)       \
-    SA_COOP_STEP(16 * (B) + 4) SA_COOP_STEP(16 * (B) + 5) SA_COOP_STEP(16 * (B) + 6) SA_COOP_STEP(16 * (B) + 7)       \
-    SA_COOP_STEP(16 * (B) + 8) SA_COOP_STEP(16 * (B) + 9) SA_COOP_STEP(16 * (B) + 10) SA_COOP_STEP(16 * (B) + 11)     \
-    SA_COOP_STEP(16 * (B) + 12) SA_COOP_STEP(16 * (B) + 13) SA_COOP_STEP(16 * (B) + 14) SA_COOP_STEP(16 * (B) + 15)   \
-    dirs[((size_t)s * blocks_cap + 4 * sb + (B)) * 64 + lane] = acc;
                 SA_COOP_BLOCK(0) SA_COOP_BLOCK(1) SA_COOP_BLOCK(2) SA_COOP_BLOCK(3)
-#undef SA_COOP_BLOCK
-#undef SA_COOP_STEP
                 // colbuf lane i = last column of row 64 sb + i - 63
                 if (more) {
                     const int r = 64 * sb + lane - 63;
@@ -221,6 +221,248 @@ __global__ void __launch_bounds__(64, 4) sa_coop_kernel(const SaPepParams P) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// A workgroup of W waves per pair, for submissions with fewer pairs than the chip has SIMDs (64 adjacent pairs of
+// 4096 residues on one wave each keep 64 of 1024 SIMDs busy).  Wave w sweeps strips w, w + W, w + 2 W ... exactly as
+// above; what changes is how a strip's last column reaches the strip to its right.  It goes through LDS, 64 rows (one
+// block) at a time, while both strips are being swept: the wave of strip s + 1 runs two blocks behind the wave of
+// strip s (it needs rows 64 b + 1 .. 64 b + 64 for its block b, which strip s completes with its block b + 1).
+//
+// Hand-over: boundary q = s mod W has a ring of SA_COOP_RING blocks and two counters, both counting blocks over all
+// the rounds of the pair: produced[q] (written by the wave of strip s) and consumed[q] (written by the wave of strip
+// s + 1).  The producer writes a block's 64 values, then the counter (release); the consumer waits for the counter
+// (acquire), reads the values, then writes its own counter (release); the producer does not overwrite a slot before
+// the block in it is consumed (acquire of that counter).
+// The boundary between the last wave and wave 0 is different: wave 0 only comes to strip W r after it has finished
+// strip W (r - 1), a whole strip later, so what wave W - 1 hands it must wait that long.  A ring there would stop wave
+// W - 1 after a few blocks, then wave W - 2 behind it, and so on down to wave 0 itself -- for ever, once a strip has
+// more blocks than the rings hold together.  That boundary therefore keeps the whole column (in LDS too, sized by the
+// longest sequence, one copy per parity of the round: wave W - 1 writes round r while wave 0 reads round r - 1) and
+// its producer never waits.  With it no wave waits in a circle: wave W - 1 depends on wave W - 2's blocks only, wave
+// W - 2 on wave W - 3's blocks and on wave W - 1 taking them, and so on; wave 0 waits for columns of the round before.
+//
+// The walk and the record's header are wave 0's; the per-row work of the record is shared by all waves.
+#define SA_COOP_RING 4
+
+// (volatile accesses to LDS are compiled as flat accesses, which wait for every global store in flight; workgroup-scope
+// atomics stay LDS instructions and cost one wait for the LDS queue)
+#define SA_LDS_ACQUIRE(X) ((uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&(X), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)))
+#define SA_LDS_RELEASE(X, V) __hip_atomic_store(&(X), (V), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP)
+
+template <int W>
+__global__ void __launch_bounds__(64 * W) sa_coop_wg_kernel(const SaPepParams P) {
+    __shared__ int32_t tab[21 * 32];
+    extern __shared__ int32_t wrapcol[];     // two whole columns of steps_cap rows: the boundary from wave W - 1 to wave 0
+    __shared__ int32_t ring[W][SA_COOP_RING][64];
+    __shared__ uint32_t produced[W], consumed[W];
+    __shared__ uint32_t item_slot;
+    __shared__ int dfinal_slot, match_slot, gap_slot;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t lslot = P.lslot;
+    const uint32_t strips_cap = lslot >> 6;
+    const uint32_t steps_cap = lslot + 128;
+    const uint32_t blocks_cap = steps_cap >> 4;
+    // per-workgroup scratch as in sa_coop_kernel (the two border columns of that layout are not used here)
+    uint8_t* const area = reinterpret_cast<uint8_t*>(P.spill) + (size_t)blockIdx.x * P.spill_rows * 1024;
+    uint32_t* const dirs = reinterpret_cast<uint32_t*>(area);
+    // the walk's notes: one dword per row (moves of the row, column it was left in), where sa_coop_kernel keeps two
+    // 16-bit arrays of the same total size
+    uint16_t* const note_l = reinterpret_cast<uint16_t*>(area + (size_t)strips_cap * blocks_cap * 256 + 2 * (size_t)steps_cap * 4);
+
+    for (int e = threadIdx.x; e < 21 * 32; e += 64 * W) {
+        const int a = e >> 5, b = e & 31;
+        int v = SA_TAG_TABLE(P.sprime[a * SA_SPRIME_STRIDE + (b <= 20 ? b : 20)]) + 1;
+        if (b == SA_COOP_NEG_CODE) v = -(1 << 29);
+        tab[e] = v;
+    }
+
+    for (;;) {
+        if (threadIdx.x == 0) { item_slot = atomicAdd(P.counter, 1u); match_slot = 0; gap_slot = 0; }
+        if (threadIdx.x < W) { produced[threadIdx.x] = 0; consumed[threadIdx.x] = 0; }
+        __syncthreads();
+        const uint32_t it = __builtin_amdgcn_readfirstlane(item_slot);
+        if (it >= P.nitems) break;
+        const SaItem item = P.items[it];
+        const uint32_t s1 = item.p, s2 = item.v0;
+        const int len1 = __builtin_amdgcn_readfirstlane((int)P.len_fo[s1]);
+        const int len2 = __builtin_amdgcn_readfirstlane((int)P.len_fo[s2]);
+        const uint8_t* const seq1 = P.codes_fo + (size_t)s1 * lslot;
+        const uint8_t* const seq2 = P.codes_fo + (size_t)s2 * lslot;
+        uint8_t* const rec = P.out + (((uint64_t)item.c0 << 32) | item.b0) * P.stride;
+        const int nstrips = (len1 + 63) >> 6;
+        const int nsuper = (len2 + 63 + 63) >> 6;
+        const int lstar = (len1 - 1) & 63;
+
+        // ------------------------------------------------------------------ fill: this wave's strips
+        const int qin = (wv + W - 1) % W;                      // boundary on this wave's left
+        const bool wrap_in = wv == 0, wrap_out = wv == W - 1;  // ... which keeps whole columns for wave 0, written by wave W - 1
+        for (int s = wv; s < nstrips; s += W) {
+            const int a32 = (int)seq1[64 * s + lane] * 32 * 4;
+            const bool first_strip = s == 0, more = s + 1 < nstrips;
+            const uint32_t gin0 = first_strip ? 0u : (uint32_t)((s - 1) / W) * (uint32_t)nsuper;     // block numbers of strip s - 1
+            const uint32_t gout0 = (uint32_t)(s / W) * (uint32_t)nsuper;                              // ... and of this strip
+            int up = 1;
+            int left = 0;
+            const int32_t* const colrd = wrapcol + (first_strip ? 0 : ((s - 1) / W) & 1) * steps_cap;
+            int32_t* const colwr = wrapcol + ((s / W) & 1) * steps_cap;
+            if (!first_strip) {
+                // row 0 of the column on the left: lane 63 of its block 0
+                while (SA_LDS_ACQUIRE(produced[qin]) < gin0 + 1) __builtin_amdgcn_s_sleep(1);
+                const int row0 = wrap_in ? colrd[0] : ring[qin][gin0 % SA_COOP_RING][63];
+                if (lane == 0) {
+                    left = row0;
+                    if (!wrap_in) SA_LDS_RELEASE(consumed[qin], gin0 + 1);
+                }
+            }
+            int left_prev = 0;
+            int b = lane == 0 ? (int)seq2[0] : SA_COOP_NEG_CODE;
+            uint32_t acc = 0;
+            int colbuf = 0;
+            int Tq[SA_COOP_AHEAD];
+#pragma unroll
+            for (int k = 0; k < SA_COOP_AHEAD; k++) {
+                Tq[k] = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(tab) + a32 + b * 4);
+                b = sa_wave_shr1(k + 1 < len2 ? (int)seq2[k + 1] : SA_COOP_NEG_CODE, b);
+            }
+            for (int sb = 0; sb < nsuper; sb++) {
+                const int rown = 64 * sb + 1 + lane;
+                const int rres = rown + SA_COOP_AHEAD;
+                const int resin = rres < len2 ? (int)seq2[rres] : SA_COOP_NEG_CODE;
+                // rows 64 sb + 1 .. 64 sb + 64 of the column on the left: its block sb + 1 (a block past the last one would
+                // hold rows below the matrix only, where the border is 0)
+                int colin = 0;
+                if (!first_strip && sb + 1 < nsuper) {
+                    const uint32_t g = gin0 + (uint32_t)sb + 1;
+                    while (SA_LDS_ACQUIRE(produced[qin]) < g + 1) __builtin_amdgcn_s_sleep(1);
+                    colin = wrap_in ? colrd[rown] : ring[qin][g % SA_COOP_RING][lane];
+                    if (lane == 0 && !wrap_in) SA_LDS_RELEASE(consumed[qin], g + 1);
+                    if (rown >= len2) colin = 0;
+                }
+                SA_COOP_BLOCK(0) SA_COOP_BLOCK(1) SA_COOP_BLOCK(2) SA_COOP_BLOCK(3)
+                // colbuf lane i = last column of row 64 sb + i - 63: block sb of this strip's boundary
+                if (more) {
+                    const uint32_t g = gout0 + (uint32_t)sb;
+                    if (wrap_out) {
+                        const int r = 64 * sb + lane - 63;
+                        if (r >= 0) colwr[r] = colbuf;
+                    } else {
+                        if (g >= SA_COOP_RING)
+                            while (SA_LDS_ACQUIRE(consumed[wv]) < g - SA_COOP_RING + 1) __builtin_amdgcn_s_sleep(1);
+                        ring[wv][g % SA_COOP_RING][lane] = colbuf;
+                    }
+                    if (lane == 0) SA_LDS_RELEASE(produced[wv], g + 1);
+                }
+            }
+            if (s == nstrips - 1 && lane == 0) dfinal_slot = __builtin_amdgcn_readlane(up, lstar) >> 2;
+        }
+        __syncthreads();      // every direction block is written
+
+        // ------------------------------------------------------------- traceback: wave 0, as in sa_coop_kernel, except
+        // that direction blocks are loaded eight at a time (blocks k, k - 1 .. k - 7 of the strip: within a strip t only
+        // ever decreases, and a diagonal path crosses a strip in about eight blocks) -- one wait for memory per window,
+        // not per block --, that a row's note goes to memory at once, as one dword (moves, column), and that runs of DIAG
+        // moves are taken several moves at a time
+        if (wv == 0) {
+            int i = len2, j = len1, run = 0;
+#ifdef SA_COOP_EXP_NO_WALK
+            i = 0;       // experiment: the fill alone (records are wrong)
+#endif
+            int cur_s = -1, cur_k = -1, win_top = -1;
+            uint32_t w = 0;                // block cur_k of strip cur_s
+            uint32_t win[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // blocks win_top .. win_top - 7 of strip cur_s
+            uint32_t* const notes = reinterpret_cast<uint32_t*>(note_l);
+            while (i > 0) {
+                int tag = SA_TAG_UP;
+                int l = 0, t = 0;
+                if (j > 0) {
+                    const int c = j - 1, sidx = c >> 6, k = (i - 1 + (c & 63)) >> 4;
+                    l = c & 63;
+                    t = i - 1 + l;
+                    if (sidx != cur_s || k != cur_k) {
+                        if (sidx != cur_s || k > win_top || k < win_top - 7) {
+                            const uint32_t* const strip_blocks = dirs + (size_t)sidx * blocks_cap * 64 + lane;
+#pragma unroll
+                            for (int q = 0; q < 8; q++) win[q] = strip_blocks[(size_t)max(k - q, 0) * 64];
+                            win_top = k;
+                        }
+                        switch (win_top - k) {
+                        case 0: w = win[0]; break;
+                        case 1: w = win[1]; break;
+                        case 2: w = win[2]; break;
+                        case 3: w = win[3]; break;
+                        case 4: w = win[4]; break;
+                        case 5: w = win[5]; break;
+                        case 6: w = win[6]; break;
+                        default: w = win[7]; break;
+                        }
+                        cur_s = sidx; cur_k = k;
+                    }
+                    tag = (int)((__builtin_amdgcn_readlane(w, l) >> (2 * (t & 15))) & 3u);
+                }
+                if (tag == SA_TAG_LEFT) { run++; j--; continue; }
+                if (tag == SA_TAG_DIAG) {
+                    // A run of DIAG moves in one go, as far as it stays in this block and strip: move m of the run
+                    // stands in lane l - m at step t - 2 m, so every lane looks at its own candidate and the run's
+                    // length is the number of consecutive hits from lane l downwards.  Lane m notes row i - 1 - m.
+                    const int mmax = min(min(l, (t & 15) >> 1), i - 1);
+                    const int m = l - lane;
+                    const uint32_t sh = (uint32_t)(2 * ((t - 2 * m) & 15));
+                    const bool hit = m >= 0 && m <= mmax && ((w >> sh) & 3u) == (uint32_t)SA_TAG_DIAG;
+                    const unsigned long long hits = __ballot(hit);                    // bit l is set: the move just read
+                    const int cnt = __builtin_clzll(~(hits << (63 - l)));
+                    if (lane < cnt) notes[i - 1 - lane] = (lane == 0 ? 2u * (uint32_t)run : 0u) | ((uint32_t)(j - 1 - lane) << 16);
+                    i -= cnt;
+                    j -= cnt;
+                    run = 0;
+                    continue;
+                }
+                if (lane == 0) notes[i - 1] = (uint32_t)(2 * run + 1) | ((uint32_t)(j > 0 ? j - 1 : 0) << 16);
+                i--;
+                run = 0;
+            }
+        }
+        __syncthreads();
+
+        // ------------------------------------------------------ record: 64 rows per wave at a time
+        int matches = 0, gaps = 0;
+        for (int r0 = 64 * wv; r0 < len2; r0 += 64 * W) {
+            const int r = r0 + lane;
+            if (r < len2) {
+                const uint32_t note = reinterpret_cast<const uint32_t*>(note_l)[r];
+                if (note & 1) gaps++;
+                else if (seq1[note >> 16] == seq2[r]) matches++;
+                *reinterpret_cast<uint16_t*>(rec + SA_LONG_HEADER_BYTES + 2 * (size_t)r) = (uint16_t)note;
+            }
+        }
+        for (uint32_t o = SA_LONG_HEADER_BYTES + 2 * (uint32_t)len2 + 2 * threadIdx.x; o + 1 < P.stride; o += 128 * W)
+            *reinterpret_cast<uint16_t*>(rec + o) = 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            matches += __shfl_xor(matches, o, 64);
+            gaps += __shfl_xor(gaps, o, 64);
+        }
+        if (lane == 0) { atomicAdd(&match_slot, matches); atomicAdd(&gap_slot, gaps); }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int score = dfinal_slot + (len1 + len2) * P.gap;
+            *reinterpret_cast<uint4*>(rec) = make_uint4((uint32_t)score, (uint32_t)match_slot, (uint32_t)gap_slot, 0u);
+        }
+        __syncthreads();          // the slots, notes and blocks are reused by the next pair
+    }
+}
+
 extern "C" void sa_launch_coop(const SaPepParams* p, unsigned grid, hipStream_t stream) {
     hipLaunchKernelGGL(sa_coop_kernel, dim3(grid), dim3(64), 0, stream, *p);
+}
+
+// waves = 2, 4, 8 or 16 waves per pair; dynamic LDS: the two whole columns, 2 x (slot + 128) x 4 bytes
+extern "C" void sa_launch_coop_wg(int waves, const SaPepParams* p, unsigned grid, hipStream_t stream) {
+    const unsigned lds = 2u * (p->lslot + 128u) * 4u;
+    switch (waves) {
+    case 2: hipLaunchKernelGGL(sa_coop_wg_kernel<2>, dim3(grid), dim3(128), lds, stream, *p); break;
+    case 4: hipLaunchKernelGGL(sa_coop_wg_kernel<4>, dim3(grid), dim3(256), lds, stream, *p); break;
+    case 8: hipLaunchKernelGGL(sa_coop_wg_kernel<8>, dim3(grid), dim3(512), lds, stream, *p); break;
+    default: hipLaunchKernelGGL(sa_coop_wg_kernel<16>, dim3(grid), dim3(1024), lds, stream, *p); break;
+    }
 }

@@ -159,8 +159,11 @@ def test_longest_supported_sequences():
     al = sa.Aligner(max_seq_len=4096)
     al.upload(seqs)
     assert al.row_bytes == 2
-    for cooperative, kernel in ((-1, "sa_long_"), (1, "sa_coop_kernel"), (0, "sa_coop_kernel")):
+    # ten pairs: left to itself the library gives each a workgroup of sixteen waves
+    for cooperative, waves, kernel in ((-1, 0, "sa_long_"), (1, 1, "sa_coop_kernel"), (0, 0, "sa_coop_wg_kernel<16>"),
+                                       (1, 2, "sa_coop_wg_kernel<2>"), (1, 8, "sa_coop_wg_kernel<8>")):
         al.set_cooperative(cooperative)
+        al.set_cooperative_waves(waves)
         rec = al.align(sa.TRIANGULAR)
         assert al.last_kernel().startswith(kernel)
         _check_pairs(al, rec, _tri_pairs(len(seqs), 0, len(seqs) - 1))
@@ -520,8 +523,10 @@ def test_long_paired_and_unpaired_kernels_give_identical_records(n, lo, hi, seed
     assert np.array_equal(paired, unpaired)
     # and the wave-per-pair kernel: the same bytes again
     al.set_cooperative(1)
-    assert np.array_equal(al.align(sa.TRIANGULAR), paired)
-    assert al.last_kernel() == "sa_coop_kernel"
+    for waves, kernel in ((1, "sa_coop_kernel"), (4, "sa_coop_wg_kernel<4>"), (16, "sa_coop_wg_kernel<16>")):
+        al.set_cooperative_waves(waves)
+        assert np.array_equal(al.align(sa.TRIANGULAR), paired), waves
+        assert al.last_kernel() == kernel
     for i in [0, n - 2] + [rng.randrange(n - 1) for _ in range(3)]:
         first = al.pair_index(sa.TRIANGULAR, i)
         pairs = [(i, j) for j in range(i + 1, n)][:40]
@@ -918,9 +923,17 @@ def test_wave_per_pair_kernel_on_awkward_shapes():
         al = sa.Aligner(gap=gap, matrix=mat, max_seq_len=1000)
         al.upload(seqs)
         al.set_cooperative(1)
+        al.set_cooperative_waves(1)
         tri = al.align(sa.TRIANGULAR)
         adj = al.align(sa.ADJACENT)
         assert al.last_kernel() == "sa_coop_kernel"
+        # a workgroup of several waves per pair: strips handed from wave to wave; 0 = the library's own choice
+        for waves in (2, 4, 8, 16, 0):
+            al.set_cooperative_waves(waves)
+            assert np.array_equal(al.align(sa.TRIANGULAR), tri), waves
+            assert al.last_kernel() == ("sa_coop_wg_kernel<%d>" % (waves or 4))       # 1 128 pairs: four waves each
+            assert np.array_equal(al.align(sa.ADJACENT), adj), waves
+            assert al.last_kernel() == ("sa_coop_wg_kernel<%d>" % (waves or 16))      # 47 pairs: sixteen
         al.set_cooperative(-1)
         assert np.array_equal(al.align(sa.TRIANGULAR), tri)
         assert np.array_equal(al.align(sa.ADJACENT), adj)

@@ -9,7 +9,9 @@ for n, lo, hi, seed, schedule in ((65, 4096, 4096, 5, sa.ADJACENT), (150, 300, 1
     al.upload(seqs)
     al.set_cooperative(1)
     rows = al.rows(schedule)
-    al.prepare_resident(schedule, 0, rows)
-    al.run_resident()
-    print(n, hi, round(min(al.run_resident() for _ in range(3)), 3), "ms", al.last_kernel(), flush=True)
+    for waves in (1, 2, 4, 8, 16, 0):
+        al.set_cooperative_waves(waves)
+        al.prepare_resident(schedule, 0, rows)
+        al.run_resident()
+        print(n, hi, "waves", waves, round(min(al.run_resident() for _ in range(3)), 3), "ms", al.last_kernel(), flush=True)
     al.close()
