@@ -271,8 +271,9 @@ def resident_measurement(sa, synth, name, device, launches=2, pairing=True, chec
 
 
 def few_pairs_measurement(sa, synth, device):
-    """Submissions of few long pairs, where a pair per lane leaves the chip idle: the wave-per-pair kernel against the
-    pair-per-lane kernel on 64 adjacent pairs of 4096-residue sequences and on 150 proteins all-vs-all."""
+    """Submissions of few long pairs, where a pair per lane leaves the chip idle: one wave per pair, a workgroup of
+    waves per pair (the library picks 1 to 16 waves from the pair count) and the pair-per-lane kernel on 64 adjacent
+    pairs of 4096-residue sequences and on 150 proteins all-vs-all."""
     out = {}
     cases = {"adjacent_65x4096": (65, 4096, 4096, 5, sa.ADJACENT), "triangular_150_proteins": (150, 300, 1000, 2, sa.TRIANGULAR)}
     for name, (n, lo, hi, seed, schedule) in cases.items():
@@ -281,8 +282,9 @@ def few_pairs_measurement(sa, synth, device):
         al.upload(seqs)
         rows = al.rows(schedule)
         res = {"pairs": al.pair_count(schedule, 0, rows), "cells": al.cell_count(schedule, 0, rows)}
-        for mode, key in ((1, "wave_per_pair"), (-1, "pair_per_lane")):
+        for mode, waves, key in ((1, 1, "wave_per_pair"), (1, 0, "workgroup_per_pair"), (-1, 0, "pair_per_lane")):
             al.set_cooperative(mode)
+            al.set_cooperative_waves(waves)
             al.prepare_resident(schedule, 0, rows)
             al.run_resident()
             ms = min(al.run_resident() for _ in range(3))

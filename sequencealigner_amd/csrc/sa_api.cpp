@@ -30,6 +30,7 @@ extern "C" void sa_launch_long_pair(const SaPepParams* p, unsigned grid, unsigne
 extern "C" void sa_launch_long_ckpt(int ck_rows, const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream);
 extern "C" void sa_launch_coop(const SaPepParams* p, unsigned grid, hipStream_t stream);
 extern "C" void sa_launch_coop_wg(int waves, const SaPepParams* p, unsigned grid, hipStream_t stream);
+extern "C" unsigned sa_coop_wg_lds_bytes(unsigned lslot, int waves);
 extern "C" void sa_launch_long(int mode, const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream);
 extern "C" void sa_launch_compact(int schedule, const uint8_t* out, uint8_t* packed, const uint64_t* cp, const uint64_t* cq,
                                   uint64_t nseq, uint64_t r0, uint64_t r1, uint32_t stride, hipStream_t stream);
@@ -431,10 +432,14 @@ bool use_coop(const sa_ctx* c, uint64_t npairs) {
 // 5.9 / 3.4 / 2.8 / 2.7, 512 such pairs 10.4 / 7.9 / 3.6 / 3.6 / 3.9, 1024: 10.6 / 8.0 / 5.3 / 5.5 / 7.4; proteins of
 // 300-1000 residues, 496 pairs 0.76 / 0.55 / 0.40 / 0.37 / 0.54, 1035 pairs 0.82 / 0.63 / 0.47 / 0.64 / 1.09, 4095 pairs
 // 1.25 / 1.15 / 1.33 / 2.19 / 4.01.
+// A workgroup's LDS (row residues, whole columns, rings, every lane's table row) grows with the waves and the sequence
+// length; 156 KiB of the CU's 160 is the most one may take.
+constexpr uint32_t kCoopLdsMax = 156u * 1024u;
 int coop_waves_for(const sa_ctx* c, uint64_t npairs) {
-    if (c->coop_waves) return c->coop_waves;
     int w = 1;
-    while (w < 16 && npairs * (uint64_t)(2 * w) <= 20ull * (uint64_t)c->ncu) w *= 2;
+    if (c->coop_waves) w = c->coop_waves;
+    else while (w < 16 && npairs * (uint64_t)(2 * w) <= 20ull * (uint64_t)c->ncu) w *= 2;
+    while (w > 1 && sa_coop_wg_lds_bytes(c->lslot, w) > kCoopLdsMax) w /= 2;
     return w;
 }
 // its scratch per workgroup, KiB: direction blocks (strips x 16-step blocks x 256 B), two border columns, row notes
@@ -549,7 +554,10 @@ int launch_work(sa_ctx* c, Work& w, bool timed) {
     const bool tri = w.schedule == SA_SCHEDULE_TRIANGULAR;
     if (w.coop) {
         const int waves = coop_waves_for(c, w.nitems);
-        const uint32_t cgrid = (uint32_t)std::min<uint64_t>(w.nitems, (uint64_t)c->ncu * 16 / waves);
+        // workgroups in flight per CU: by wave slots, and for several waves per pair by LDS
+        uint64_t wg_per_cu = 16 / waves;
+        if (waves > 1) wg_per_cu = std::max<uint64_t>(1, std::min<uint64_t>(wg_per_cu, (160u * 1024u) / (sa_coop_wg_lds_bytes(c->lslot, waves) + 4096u)));
+        const uint32_t cgrid = (uint32_t)std::min<uint64_t>(w.nitems, (uint64_t)c->ncu * wg_per_cu);
         const uint32_t kib = coop_kib_per_wg(c);
         if ((rc = c->d_coop.reserve((size_t)cgrid * kib * 1024))) return rc;
         P.spill = (uint32_t*)c->d_coop.p;

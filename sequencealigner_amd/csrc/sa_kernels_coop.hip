@@ -249,11 +249,23 @@ __global__ void __launch_bounds__(64, 4) sa_coop_kernel(const SaPepParams P) {
 #define SA_LDS_ACQUIRE(X) ((uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&(X), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)))
 #define SA_LDS_RELEASE(X, V) __hip_atomic_store(&(X), (V), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP)
 
+// Dynamic LDS of sa_coop_wg_kernel, byte offsets (slot = padded sequence length, steps = slot + 128):
+//   row residues  slot + 208 bytes: sequence 2 with 64 codes of "above the matrix" before it and as many as the steps
+//                 (and the requests that run ahead of them) reach after it
+//   zeros         64 dwords: the border column of the first strip and of rows below the matrix
+//   whole columns 2 x (64 + steps) dwords (64 in front: the rows above the matrix that lane 63 also computes)
+//   rings         W x SA_COOP_RING x 64 dwords
+//   lane tables   W x 22 x 64 dwords: every lane's own row of the score table, entry b of lane l at (b * 64 + l) * 4,
+//                 so that a wave's 64 reads go to 64 different addresses in bank order whatever the residues are
+__host__ __device__ inline uint32_t sa_cwg_rowres_bytes(uint32_t lslot) { return (lslot + 208u) & ~15u; }
+__host__ __device__ inline uint32_t sa_cwg_lds_bytes(uint32_t lslot, uint32_t waves) {
+    return sa_cwg_rowres_bytes(lslot) + 256u + 2u * (64u + lslot + 128u) * 4u + waves * SA_COOP_RING * 256u + waves * 22u * 256u;
+}
+
 template <int W>
 __global__ void __launch_bounds__(64 * W) sa_coop_wg_kernel(const SaPepParams P) {
     __shared__ int32_t tab[21 * 32];
-    extern __shared__ int32_t wrapcol[];     // two whole columns of steps_cap rows: the boundary from wave W - 1 to wave 0
-    __shared__ int32_t ring[W][SA_COOP_RING][64];
+    extern __shared__ __align__(16) uint8_t smem[];
     __shared__ uint32_t produced[W], consumed[W];
     __shared__ uint32_t item_slot;
     __shared__ int dfinal_slot, match_slot, gap_slot;
@@ -263,6 +275,11 @@ __global__ void __launch_bounds__(64 * W) sa_coop_wg_kernel(const SaPepParams P)
     const uint32_t strips_cap = lslot >> 6;
     const uint32_t steps_cap = lslot + 128;
     const uint32_t blocks_cap = steps_cap >> 4;
+    const uint32_t off_zeros = sa_cwg_rowres_bytes(lslot);
+    const uint32_t off_wrap = off_zeros + 256;
+    const uint32_t wrap_bytes = (64 + steps_cap) * 4;
+    const uint32_t off_ring = off_wrap + 2 * wrap_bytes;
+    const uint32_t off_ltab = off_ring + W * SA_COOP_RING * 256;
     // per-workgroup scratch as in sa_coop_kernel (the two border columns of that layout are not used here)
     uint8_t* const area = reinterpret_cast<uint8_t*>(P.spill) + (size_t)blockIdx.x * P.spill_rows * 1024;
     uint32_t* const dirs = reinterpret_cast<uint32_t*>(area);
@@ -270,6 +287,7 @@ __global__ void __launch_bounds__(64 * W) sa_coop_wg_kernel(const SaPepParams P)
     // 16-bit arrays of the same total size
     uint16_t* const note_l = reinterpret_cast<uint16_t*>(area + (size_t)strips_cap * blocks_cap * 256 + 2 * (size_t)steps_cap * 4);
 
+    if (threadIdx.x < 64) reinterpret_cast<int32_t*>(smem + off_zeros)[threadIdx.x] = 0;
     for (int e = threadIdx.x; e < 21 * 32; e += 64 * W) {
         const int a = e >> 5, b = e & 31;
         int v = SA_TAG_TABLE(P.sprime[a * SA_SPRIME_STRIDE + (b <= 20 ? b : 20)]) + 1;
@@ -294,64 +312,119 @@ __global__ void __launch_bounds__(64 * W) sa_coop_wg_kernel(const SaPepParams P)
         const int nsuper = (len2 + 63 + 63) >> 6;
         const int lstar = (len1 - 1) & 63;
 
+        // sequence 2 for every wave: code of row r at byte 64 + r; outside the matrix the code whose scores are hugely negative
+        for (uint32_t o = threadIdx.x; o < off_zeros; o += 64 * W) {
+            const int r = (int)o - 64;
+            smem[o] = (r >= 0 && r < len2) ? seq2[r] : (uint8_t)SA_COOP_NEG_CODE;
+        }
+        __syncthreads();
+
         // ------------------------------------------------------------------ fill: this wave's strips
+        // A step costs nine vector instructions (table address, DIAG sum, maximum, tag shifted in, clean value, UP
+        // operand, LEFT operand by DPP, lane 63's value into the column register by v_readlane + v_writelane) and three
+        // LDS reads, each with a literal offset off a per-block address: the row residue (a byte, four steps ahead), the
+        // table entry (two steps ahead), and the border value of the row lane 0 comes to next (the same address for all
+        // lanes; it lands in the register that the DPP move then fills for lanes 1 .. 63).  Nothing travels from lane to
+        // lane but the LEFT operand.  Sixteen waves issue these nine at four cycles each: 9 cycles per step and CU, which
+        // is what the fill of a 4096 x 4096 pair takes (270 000 steps, 1.17 ms).  With the last-column value stored to LDS
+        // at every step instead (seven vector, four LDS instructions) the LDS is the limit: 1.38 ms.
         const int qin = (wv + W - 1) % W;                      // boundary on this wave's left
         const bool wrap_in = wv == 0, wrap_out = wv == W - 1;  // ... which keeps whole columns for wave 0, written by wave W - 1
+        const uint32_t ltab_lane = off_ltab + (uint32_t)wv * 22 * 256 + (uint32_t)lane * 4;
         for (int s = wv; s < nstrips; s += W) {
-            const int a32 = (int)seq1[64 * s + lane] * 32 * 4;
+            {   // this lane's row of the table
+                const int a = (int)seq1[64 * s + lane];
+#pragma unroll
+                for (int b = 0; b < 22; b++) *reinterpret_cast<int32_t*>(smem + ltab_lane + b * 256) = tab[a * 32 + b];
+            }
             const bool first_strip = s == 0, more = s + 1 < nstrips;
             const uint32_t gin0 = first_strip ? 0u : (uint32_t)((s - 1) / W) * (uint32_t)nsuper;     // block numbers of strip s - 1
             const uint32_t gout0 = (uint32_t)(s / W) * (uint32_t)nsuper;                              // ... and of this strip
+            const uint32_t wrap_rd = off_wrap + (first_strip ? 0u : (uint32_t)(((s - 1) / W) & 1)) * wrap_bytes + 256;   // row 0
+            const uint32_t wrap_wr = off_wrap + (uint32_t)((s / W) & 1) * wrap_bytes + 256;
             int up = 1;
             int left = 0;
-            const int32_t* const colrd = wrapcol + (first_strip ? 0 : ((s - 1) / W) & 1) * steps_cap;
-            int32_t* const colwr = wrapcol + ((s / W) & 1) * steps_cap;
             if (!first_strip) {
-                // row 0 of the column on the left: lane 63 of its block 0
+                // row 0 of the column on the left: entry 63 of its block 0
                 while (SA_LDS_ACQUIRE(produced[qin]) < gin0 + 1) __builtin_amdgcn_s_sleep(1);
-                const int row0 = wrap_in ? colrd[0] : ring[qin][gin0 % SA_COOP_RING][63];
+                const int row0 = *reinterpret_cast<const int32_t*>(smem + (wrap_in ? wrap_rd : off_ring + ((uint32_t)qin * SA_COOP_RING + gin0 % SA_COOP_RING) * 256 + 63 * 4));
                 if (lane == 0) {
                     left = row0;
                     if (!wrap_in) SA_LDS_RELEASE(consumed[qin], gin0 + 1);
                 }
             }
             int left_prev = 0;
-            int b = lane == 0 ? (int)seq2[0] : SA_COOP_NEG_CODE;
             uint32_t acc = 0;
             int colbuf = 0;
-            int Tq[SA_COOP_AHEAD];
-#pragma unroll
-            for (int k = 0; k < SA_COOP_AHEAD; k++) {
-                Tq[k] = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(tab) + a32 + b * 4);
-                b = sa_wave_shr1(k + 1 < len2 ? (int)seq2[k + 1] : SA_COOP_NEG_CODE, b);
+            // residues of steps 2 and 3 and table entries of steps 0 and 1 are under way when the first step begins
+            uint32_t res_off = 64u - (uint32_t)lane;            // byte of the residue of step 64 sb for this lane
+            int Tq0, Tq1, Ba, Bb;
+            {
+                const int b0 = smem[res_off], b1 = smem[res_off + 1];
+                Ba = smem[res_off + 2];
+                Bb = smem[res_off + 3];
+                Tq0 = *reinterpret_cast<const int32_t*>(smem + ltab_lane + (b0 << 8));
+                Tq1 = *reinterpret_cast<const int32_t*>(smem + ltab_lane + (b1 << 8));
             }
             for (int sb = 0; sb < nsuper; sb++) {
-                const int rown = 64 * sb + 1 + lane;
-                const int rres = rown + SA_COOP_AHEAD;
-                const int resin = rres < len2 ? (int)seq2[rres] : SA_COOP_NEG_CODE;
-                // rows 64 sb + 1 .. 64 sb + 64 of the column on the left: its block sb + 1 (a block past the last one would
-                // hold rows below the matrix only, where the border is 0)
-                int colin = 0;
+                // border values of rows 64 sb + 1 .. 64 sb + 64: block sb + 1 of the column on the left (a block past its
+                // last one would hold rows below the matrix only: zeros do there, as in the first strip)
+                uint32_t bord_off = off_zeros, gin = 0;
+                bool give_back = false;
                 if (!first_strip && sb + 1 < nsuper) {
-                    const uint32_t g = gin0 + (uint32_t)sb + 1;
-                    while (SA_LDS_ACQUIRE(produced[qin]) < g + 1) __builtin_amdgcn_s_sleep(1);
-                    colin = wrap_in ? colrd[rown] : ring[qin][g % SA_COOP_RING][lane];
-                    if (lane == 0 && !wrap_in) SA_LDS_RELEASE(consumed[qin], g + 1);
-                    if (rown >= len2) colin = 0;
+                    gin = gin0 + (uint32_t)sb + 1;
+                    while (SA_LDS_ACQUIRE(produced[qin]) < gin + 1) __builtin_amdgcn_s_sleep(1);
+                    bord_off = wrap_in ? wrap_rd + (64u * sb + 1) * 4 : off_ring + ((uint32_t)qin * SA_COOP_RING + gin % SA_COOP_RING) * 256;
+                    give_back = !wrap_in;
                 }
-                SA_COOP_BLOCK(0) SA_COOP_BLOCK(1) SA_COOP_BLOCK(2) SA_COOP_BLOCK(3)
-                // colbuf lane i = last column of row 64 sb + i - 63: block sb of this strip's boundary
+                const uint32_t gout = gout0 + (uint32_t)sb;
+                int Xq0 = *reinterpret_cast<const int32_t*>(smem + bord_off);
+                int Xq1 = *reinterpret_cast<const int32_t*>(smem + bord_off + 4);
+#define SA_CWG_STEP(TL)                                                                                               \
+    {                                                                                                                 \
+        const int Bn = smem[res_off + (TL) + 4];                                                                      \
+        const int Tn = *reinterpret_cast<const int32_t*>(smem + ltab_lane + ((uint32_t)Ba << 8));                     \
+        int Xn = 0;                                                                                                   \
+        if ((TL) + 2 < 64) Xn = *reinterpret_cast<const int32_t*>(smem + bord_off + 4 * ((TL) + 2));                  \
+        const int m = left_prev + Tq0;                                                                                \
+        const int h = max3i(m, up, left);                                                                             \
+        acc = __builtin_amdgcn_alignbit((uint32_t)h, acc, 2);                                                         \
+        const int zl = h & ~3;                                                                                        \
+        up = zl | 1;                                                                                                  \
+        /* the strip's last column, row t - 63, for the strip on the right */                                         \
+        const int last = __builtin_amdgcn_readlane(zl, 63);                                                           \
+        SA_WRITELANE_CONST(colbuf, last, (TL));                                                                       \
+        left_prev = left;                                                                                             \
+        /* next step's LEFT: from the lane on the left; lane 0 keeps the border value the register already holds */   \
+        left = __builtin_amdgcn_update_dpp(Xq0, zl, SA_COOP_DPP_WAVE_SHR1, 0xf, 0xf, false);                          \
+        Tq0 = Tq1; Tq1 = Tn; Ba = Bb; Bb = Bn; Xq0 = Xq1; Xq1 = Xn;                                                   \
+    }
+#define SA_CWG_BLOCK(B)                                                                                               \
+    SA_CWG_STEP(16 * (B) + 0) SA_CWG_STEP(16 * (B) + 1) SA_CWG_STEP(16 * (B) + 2) SA_CWG_STEP(16 * (B) + 3)           \
+    SA_CWG_STEP(16 * (B) + 4) SA_CWG_STEP(16 * (B) + 5) SA_CWG_STEP(16 * (B) + 6) SA_CWG_STEP(16 * (B) + 7)           \
+    SA_CWG_STEP(16 * (B) + 8) SA_CWG_STEP(16 * (B) + 9) SA_CWG_STEP(16 * (B) + 10) SA_CWG_STEP(16 * (B) + 11)         \
+    SA_CWG_STEP(16 * (B) + 12) SA_CWG_STEP(16 * (B) + 13) SA_CWG_STEP(16 * (B) + 14) SA_CWG_STEP(16 * (B) + 15)       \
+    dirs[((size_t)s * blocks_cap + 4 * sb + (B)) * 64 + lane] = acc;
+                SA_CWG_BLOCK(0) SA_CWG_BLOCK(1) SA_CWG_BLOCK(2) SA_CWG_BLOCK(3)
+#undef SA_CWG_BLOCK
+#undef SA_CWG_STEP
+                res_off += 64;
+                // colbuf lane i = last column of row 64 sb + i - 63: block sb of the boundary on the right
                 if (more) {
-                    const uint32_t g = gout0 + (uint32_t)sb;
+                    uint32_t mine;
                     if (wrap_out) {
-                        const int r = 64 * sb + lane - 63;
-                        if (r >= 0) colwr[r] = colbuf;
+                        mine = wrap_wr + (uint32_t)((64 * sb - 63) * 4);
                     } else {
-                        if (g >= SA_COOP_RING)
-                            while (SA_LDS_ACQUIRE(consumed[wv]) < g - SA_COOP_RING + 1) __builtin_amdgcn_s_sleep(1);
-                        ring[wv][g % SA_COOP_RING][lane] = colbuf;
+                        if (gout >= SA_COOP_RING)
+                            while (SA_LDS_ACQUIRE(consumed[wv]) < gout - SA_COOP_RING + 1) __builtin_amdgcn_s_sleep(1);
+                        mine = off_ring + ((uint32_t)wv * SA_COOP_RING + gout % SA_COOP_RING) * 256;
                     }
-                    if (lane == 0) SA_LDS_RELEASE(produced[wv], g + 1);
+                    *reinterpret_cast<int32_t*>(smem + mine + (uint32_t)lane * 4) = colbuf;
+                }
+                // the block is written: the wave on the right may read it; the block read is free for its writer
+                if (lane == 0) {
+                    if (more) SA_LDS_RELEASE(produced[wv], gout + 1);
+                    if (give_back) SA_LDS_RELEASE(consumed[qin], gin + 1);
                 }
             }
             if (s == nstrips - 1 && lane == 0) dfinal_slot = __builtin_amdgcn_readlane(up, lstar) >> 2;
@@ -456,9 +529,18 @@ extern "C" void sa_launch_coop(const SaPepParams* p, unsigned grid, hipStream_t 
     hipLaunchKernelGGL(sa_coop_kernel, dim3(grid), dim3(64), 0, stream, *p);
 }
 
-// waves = 2, 4, 8 or 16 waves per pair; dynamic LDS: the two whole columns, 2 x (slot + 128) x 4 bytes
+// dynamic LDS of a workgroup of `waves` waves for sequences padded to `lslot` (the kernel has 3 KiB of its own on top)
+extern "C" unsigned sa_coop_wg_lds_bytes(unsigned lslot, int waves) { return sa_cwg_lds_bytes(lslot, (uint32_t)waves); }
+
+// waves = 2, 4, 8 or 16 waves per pair
 extern "C" void sa_launch_coop_wg(int waves, const SaPepParams* p, unsigned grid, hipStream_t stream) {
-    const unsigned lds = 2u * (p->lslot + 128u) * 4u;
+    const unsigned lds = sa_cwg_lds_bytes(p->lslot, (uint32_t)waves);
+    // more than 64 KiB of dynamic LDS has to be asked for (per device, so at every launch; a refusal shows at the launch)
+    if (lds > 48u * 1024u) {
+        const void* f = waves == 2 ? (const void*)sa_coop_wg_kernel<2> : waves == 4 ? (const void*)sa_coop_wg_kernel<4>
+                      : waves == 8 ? (const void*)sa_coop_wg_kernel<8> : (const void*)sa_coop_wg_kernel<16>;
+        (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
     switch (waves) {
     case 2: hipLaunchKernelGGL(sa_coop_wg_kernel<2>, dim3(grid), dim3(128), lds, stream, *p); break;
     case 4: hipLaunchKernelGGL(sa_coop_wg_kernel<4>, dim3(grid), dim3(256), lds, stream, *p); break;
