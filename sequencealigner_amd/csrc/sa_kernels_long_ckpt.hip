@@ -436,6 +436,7 @@ __global__ void __launch_bounds__(64, 4) sa_long_ckpt_kernel(const SaPepParams P
                         return first_strip ? make_uint4(0, 0, 0, 0) : bin[(size_t)(min(r, rows_last - 3) >> 2) * 64];
                     };
                     auto rel = [&](uint32_t w) -> uint32_t { return lck_pk_shl4(lck_pk_sub(w, base12)); };
+                    const int tnA = t0 ? wi[0] - 1 - r0 : -1, tnB = t1 ? wi[1] - 1 - r0 : -1;
                     auto store_dirs = [&](int t) {
                         uint32_t lo[4], hi[4];
 #pragma unroll
@@ -444,8 +445,10 @@ __global__ void __launch_bounds__(64, 4) sa_long_ckpt_kernel(const SaPepParams P
                             lo[k] = __builtin_amdgcn_perm(w0, w1, 0x05040100u);     // low halves:  w0.lo : w1.lo
                             hi[k] = __builtin_amdgcn_perm(w0, w1, 0x07060302u);     // high halves: w0.hi : w1.hi
                         }
-                        *reinterpret_cast<uint4*>(drowA + (size_t)t * 256) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
-                        *reinterpret_cast<uint4*>(drowB + (size_t)t * 256) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+                        // a lane keeps the rows its own paths can reach: up to the row each stands in (the wave fills the
+                        // tile as far as its lowest path needs)
+                        if (t <= tnA) *reinterpret_cast<uint4*>(drowA + (size_t)t * 256) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+                        if (t <= tnB) *reinterpret_cast<uint4*>(drowB + (size_t)t * 256) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
                     };
                     uint32_t bres = residues4(r0);
                     uint4 bord = border4(r0);
@@ -497,21 +500,33 @@ __global__ void __launch_bounds__(64, 4) sa_long_ckpt_kernel(const SaPepParams P
                     sa_u32x4v a0x, a1x, a2x, a3x, a4x, a5x, a6x, a7x, b0x, b1x, b2x, b3x, b4x, b5x, b6x, b7x;
                     sa_u32x2v rx;
 #define SA_LCK_FETCH(CH)                                                                                                 \
-    asm volatile("global_load_dwordx4 %0, %17, %18\n\tglobal_load_dwordx4 %1, %17, %18 offset:1024\n\t"                  \
-                 "global_load_dwordx4 %2, %17, %18 offset:2048\n\tglobal_load_dwordx4 %3, %17, %18 offset:3072\n\t"      \
-                 "global_load_dwordx4 %4, %17, %19\n\tglobal_load_dwordx4 %5, %17, %19 offset:1024\n\t"                  \
-                 "global_load_dwordx4 %6, %17, %19 offset:2048\n\tglobal_load_dwordx4 %7, %17, %19 offset:3072\n\t"      \
-                 "global_load_dwordx4 %8, %17, %20\n\tglobal_load_dwordx4 %9, %17, %20 offset:1024\n\t"                  \
-                 "global_load_dwordx4 %10, %17, %20 offset:2048\n\tglobal_load_dwordx4 %11, %17, %20 offset:3072\n\t"    \
-                 "global_load_dwordx4 %12, %17, %21\n\tglobal_load_dwordx4 %13, %17, %21 offset:1024\n\t"                \
-                 "global_load_dwordx4 %14, %17, %21 offset:2048\n\tglobal_load_dwordx4 %15, %17, %21 offset:3072\n\t"    \
-                 "global_load_dwordx2 %16, %22, off\n\t"                                                                 \
+    {                                                                                                                    \
+        /* a lane asks for the rows of a half only if its path of that half stands in or below this chunk: the other   \
+           lanes' rows were not stored either */                                                                         \
+        const unsigned long long needA_ = __ballot(tc0 >= 8 * (CH)), needB_ = __ballot(tc1 >= 8 * (CH));                 \
+        unsigned long long all_;                                                                                         \
+        asm volatile("s_mov_b64 %[all], exec\n\t"                                                                        \
+                 "s_and_b64 exec, %[all], %[na]\n\t"                                                                     \
+                 "global_load_dwordx4 %0, %[vo], %[a0]\n\tglobal_load_dwordx4 %1, %[vo], %[a0] offset:1024\n\t"          \
+                 "global_load_dwordx4 %2, %[vo], %[a0] offset:2048\n\tglobal_load_dwordx4 %3, %[vo], %[a0] offset:3072\n\t" \
+                 "global_load_dwordx4 %4, %[vo], %[a1]\n\tglobal_load_dwordx4 %5, %[vo], %[a1] offset:1024\n\t"          \
+                 "global_load_dwordx4 %6, %[vo], %[a1] offset:2048\n\tglobal_load_dwordx4 %7, %[vo], %[a1] offset:3072\n\t" \
+                 "s_and_b64 exec, %[all], %[nb]\n\t"                                                                     \
+                 "global_load_dwordx4 %8, %[vo], %[b0]\n\tglobal_load_dwordx4 %9, %[vo], %[b0] offset:1024\n\t"          \
+                 "global_load_dwordx4 %10, %[vo], %[b0] offset:2048\n\tglobal_load_dwordx4 %11, %[vo], %[b0] offset:3072\n\t" \
+                 "global_load_dwordx4 %12, %[vo], %[b1]\n\tglobal_load_dwordx4 %13, %[vo], %[b1] offset:1024\n\t"        \
+                 "global_load_dwordx4 %14, %[vo], %[b1] offset:2048\n\tglobal_load_dwordx4 %15, %[vo], %[b1] offset:3072\n\t" \
+                 "s_mov_b64 exec, %[all]\n\t"                                                                            \
+                 "global_load_dwordx2 %16, %[rp], off\n\t"                                                               \
                  "s_waitcnt vmcnt(0)"                                                                                    \
                  : "=&v"(a0x), "=&v"(a1x), "=&v"(a2x), "=&v"(a3x), "=&v"(a4x), "=&v"(a5x), "=&v"(a6x), "=&v"(a7x),        \
-                   "=&v"(b0x), "=&v"(b1x), "=&v"(b2x), "=&v"(b3x), "=&v"(b4x), "=&v"(b5x), "=&v"(b6x), "=&v"(b7x), "=&v"(rx) \
-                 : "v"(voff), "s"(tile_a + (size_t)(CH) * 8192), "s"(tile_a + (size_t)(CH) * 8192 + 4096),               \
-                   "s"(tile_b + (size_t)(CH) * 8192), "s"(tile_b + (size_t)(CH) * 8192 + 4096), "v"(resp + 8 * (CH))      \
-                 : "memory")
+                   "=&v"(b0x), "=&v"(b1x), "=&v"(b2x), "=&v"(b3x), "=&v"(b4x), "=&v"(b5x), "=&v"(b6x), "=&v"(b7x), "=&v"(rx), \
+                   [all] "=&s"(all_)                                                                                     \
+                 : [vo] "v"(voff), [a0] "s"(tile_a + (size_t)(CH) * 8192), [a1] "s"(tile_a + (size_t)(CH) * 8192 + 4096), \
+                   [b0] "s"(tile_b + (size_t)(CH) * 8192), [b1] "s"(tile_b + (size_t)(CH) * 8192 + 4096),                 \
+                   [rp] "v"(resp + 8 * (CH)), [na] "s"(needA_), [nb] "s"(needB_)                                          \
+                 : "memory");                                                                                            \
+    }
 #define SA_LCK_STEP(H, TC, D, REC)                                                                                         \
     if ((TC) == t) {                                                                                                       \
         const int jl = wj[H] - cbase;                         /* columns of this strip still to go: 1 .. 64 */             \
