@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -198,11 +199,17 @@ bool packed_cells_fit(const sa_ctx* c, bool lng) {
     return span * c->sprime_max <= 1983;
 }
 
-// Bucket order of the sequences and the cursor table (see sa_device.h); TRIANGULAR only.
+// len_suffix[i] = sum of len[i ..]
 void ensure_suffix(sa_ctx* c) {
-    if (c->len_suffix.size() == c->nseq + 1) return;
-    c->len_suffix.assign(c->nseq + 1, 0);
-    for (uint64_t s = c->nseq; s-- > 0;) c->len_suffix[s] = c->len_suffix[s + 1] + c->len[s];
+    const uint64_t n = c->nseq;
+    if (c->len_suffix.size() == n + 1) return;
+    c->len_suffix.resize(n + 1);
+    uint64_t* const v = c->len_suffix.data();
+    prefix_sums(n, v, [&](uint64_t s) { return (uint64_t)c->len[s]; });
+    const uint64_t total = v[n];
+    sa_parallel_for(n + 1, 1 << 16, [&](uint64_t lo, uint64_t hi, unsigned) {
+        for (uint64_t s = lo; s < hi; s++) v[s] = total - v[s];
+    });
 }
 
 // packed record of a pair whose second sequence has `len` residues: header + one code per row, rounded up to 4 bytes
@@ -214,11 +221,12 @@ inline uint32_t packed_record_bytes(const sa_ctx* c, uint32_t len) {
 // TRIANGULAR rows of first sequences 0 .. i-1 (row i holds second sequences i+1 .. n-1)
 void build_compact_tables(sa_ctx* c) {
     const uint64_t n = c->nseq;
-    c->cp.assign(n + 2, 0);
-    for (uint64_t s = 0; s < n; s++) c->cp[s + 1] = c->cp[s] + packed_record_bytes(c, c->len[s]);
+    c->cp.resize(n + 2);
+    prefix_sums(n, c->cp.data(), [&](uint64_t s) { return (uint64_t)packed_record_bytes(c, c->len[s]); });
     c->cp[n + 1] = c->cp[n];
-    c->cq.assign(n + 1, 0);
-    for (uint64_t i = 0; i < n; i++) c->cq[i + 1] = c->cq[i] + (i + 1 <= n ? c->cp[n] - c->cp[i + 1] : 0);
+    c->cq.resize(n + 1);
+    const uint64_t all = c->cp[n];
+    prefix_sums(n, c->cq.data(), [&](uint64_t i) { return all - c->cp[i + 1]; });
     c->compact_on_device = false;
 }
 int ensure_compact_on_device(sa_ctx* c) {
@@ -1115,18 +1123,31 @@ int sa_upload_passthrough(sa_ctx* c, const char* bytes, const uint64_t* offs, ui
     if (c->device == SA_DEVICE_NONE || nseq != c->nseq) return SA_ERR_STATE;
     if (offs[nseq] >= 0xFFFFFFF0ull) return SA_ERR_NOMEM;
     SA_HIP_TRY(hipSetDevice(c->device));
-    std::vector<uint32_t> o32(nseq + 1);
+    std::unique_ptr<uint32_t[]> o32(new (std::nothrow) uint32_t[nseq + 1]);
+    if (!o32) return SA_ERR_NOMEM;
+    std::vector<uint32_t> longest_of(sa_host_threads(), 0);
+    std::vector<int> bad_of(sa_host_threads(), 0);
+    sa_parallel_for(nseq + 1, 1 << 16, [&](uint64_t lo, uint64_t hi, unsigned t) {
+        uint32_t longest = 0;
+        int bad = 0;
+        for (uint64_t s = lo; s < hi; s++) {
+            o32[s] = (uint32_t)offs[s];
+            if (s && offs[s] < offs[s - 1]) bad = 1;
+            if (s) longest = std::max(longest, (uint32_t)(offs[s] - offs[s - 1]));
+        }
+        longest_of[t] = longest;
+        bad_of[t] = bad;
+    });
     uint32_t longest = 0;
-    for (uint64_t s = 0; s <= nseq; s++) {
-        o32[s] = (uint32_t)offs[s];
-        if (s && offs[s] < offs[s - 1]) return SA_ERR_ARG;
-        if (s) longest = std::max(longest, (uint32_t)(offs[s] - offs[s - 1]));
+    for (unsigned t = 0; t < longest_of.size(); t++) {
+        if (bad_of[t]) return SA_ERR_ARG;
+        longest = std::max(longest, longest_of[t]);
     }
     int rc;
     if ((rc = c->d_other.reserve(std::max<size_t>(16, offs[nseq])))) return rc;
-    if ((rc = c->d_other_off.reserve(o32.size() * 4))) return rc;
+    if ((rc = c->d_other_off.reserve((nseq + 1) * 4))) return rc;
     if (offs[nseq]) SA_HIP_TRY(hipMemcpy(c->d_other.p, bytes, offs[nseq], hipMemcpyHostToDevice));
-    SA_HIP_TRY(hipMemcpy(c->d_other_off.p, o32.data(), o32.size() * 4, hipMemcpyHostToDevice));
+    SA_HIP_TRY(hipMemcpy(c->d_other_off.p, o32.get(), (nseq + 1) * 4, hipMemcpyHostToDevice));
     c->max_other = longest;
     c->other_set = true;
     return SA_OK;

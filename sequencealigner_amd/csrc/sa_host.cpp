@@ -553,14 +553,21 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
             tl.ncols = L.ncols;
             for (uint32_t k = 0; k < L.ncols && k < 32; k++) tl.kind[k] = (int8_t)L.kind[k];
             snprintf(tl.align_fmt, sizeof(tl.align_fmt), "%s", st->write_csv_align_fmt);
-            std::vector<uint64_t> ooff(n + 1, 0);
-            for (uint64_t s = 0; s < n; s++) ooff[s + 1] = ooff[s] + tab.rows[s].other_len;
-            std::vector<char> obytes(ooff[n] + 1);
-            sa_parallel_for(n, 1 << 16, [&](uint64_t lo, uint64_t hi, unsigned) {
-                for (uint64_t s = lo; s < hi; s++) memcpy(obytes.data() + ooff[s], tab.rows[s].other, tab.rows[s].other_len);
-            });
-            rc = sa_set_text_layout(ctx[0], &tl);
-            if (rc == SA_OK) rc = sa_upload_passthrough(ctx[0], obytes.data(), ooff.data(), n);
+            // plain arrays again: nothing cleared on one thread before the threads fill it
+            std::unique_ptr<uint64_t[]> ooff(new (std::nothrow) uint64_t[n + 1]);
+            std::unique_ptr<char[]> obytes;
+            if (ooff) {
+                prefix_sums(n, ooff.get(), [&](uint64_t s) { return (uint64_t)tab.rows[s].other_len; });
+                obytes.reset(new (std::nothrow) char[ooff[n] + 1]);
+            }
+            if (!ooff || !obytes) rc = SA_ERR_NOMEM;
+            if (rc == SA_OK) {
+                sa_parallel_for(n, 1 << 16, [&](uint64_t lo, uint64_t hi, unsigned) {
+                    for (uint64_t s = lo; s < hi; s++) memcpy(obytes.get() + ooff[s], tab.rows[s].other, tab.rows[s].other_len);
+                });
+                rc = sa_set_text_layout(ctx[0], &tl);
+            }
+            if (rc == SA_OK) rc = sa_upload_passthrough(ctx[0], obytes.get(), ooff.get(), n);
         }
         if (rc == SA_OK && ndev > 1) {
             rc = sa_prepare_schedule(ctx[0], schedule);

@@ -26,4 +26,23 @@ unsigned sa_parallel_for(uint64_t n, uint64_t grain, F f) {
     return T;
 }
 
+// out[0] = 0, out[s + 1] = out[s] + val(s) for s in [0, n), on the host threads: slice sums, then every slice from its
+// start value (the 4 001 280-row data set: three such sums took 17 ms of its upload on one thread)
+template <class F>
+void prefix_sums(uint64_t n, uint64_t* out, F val) {
+    std::vector<uint64_t> start(sa_host_threads() + 1, 0);
+    sa_parallel_for(n, 1 << 16, [&](uint64_t lo, uint64_t hi, unsigned t) {
+        uint64_t a = 0;
+        for (uint64_t s = lo; s < hi; s++) a += val(s);
+        start[t + 1] = a;
+    });
+    for (size_t t = 1; t < start.size(); t++) start[t] += start[t - 1];
+    out[0] = 0;
+    sa_parallel_for(n, 1 << 16, [&](uint64_t lo, uint64_t hi, unsigned t) {
+        uint64_t a = start[t];
+        for (uint64_t s = lo; s < hi; s++) { a += val(s); out[s + 1] = a; }
+    });
+}
+
+
 #endif

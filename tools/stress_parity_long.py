@@ -4,7 +4,7 @@ Each case draws a table that keeps the packed kernel in range (shifted scores 1.
 letters (small ones give long runs of gaps and many ties), 70-260 sequences and a wide length range (65 .. 1500: pairs
 whose lengths differ by a factor of ten have runs of LEFT or UP moves hundreds of columns long, which cross several
 64-column strips in one row); every record of the all-vs-all schedule is compared between the packed and the 32-bit
-kernel, and a sample of pairs with the checker."""
+kernel and the wave-per-pair kernels (one wave, a workgroup of waves), and a sample of pairs with the checker."""
 import os, random, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -43,6 +43,16 @@ for seed in range(first, first + count):
     unpaired = al.align(sa.TRIANGULAR)
     kernel2 = al.last_kernel()
     same = np.array_equal(paired, unpaired)
+    # the wave-per-pair kernel and a workgroup of waves per pair: the same bytes again
+    al.set_cooperative(1)
+    coop_ok = True
+    for waves in (1, rng.choice([2, 4, 8, 16]), 0):
+        al.set_cooperative_waves(waves)
+        if not np.array_equal(al.align(sa.TRIANGULAR), unpaired):
+            coop_ok = False
+            print("  wave-per-pair kernel differs", seed, waves, al.last_kernel(), flush=True)
+    al.set_cooperative(-1)
+    same = same and coop_ok
     ok = True
     for _ in range(60):
         i = rng.randrange(n - 1)
