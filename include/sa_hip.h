@@ -196,7 +196,10 @@ int sa_set_pairing(sa_ctx* ctx, int enable);
  * 32: the fill keeps values only and leaves a checkpoint (one matrix row per strip) every `rows` rows plus the last
  * column of every strip; the traceback fills again, with direction tags, only the tiles its path goes through.
  * rows = 0: the fill writes two direction bits for every cell and the traceback reads them back (the earlier kernel;
- * four times the scratch memory).  Same records either way. */
+ * four times the scratch memory).  SA_LONG_CHECKPOINT_AUTO (the default): 64 when the longest uploaded sequence has
+ * 512 residues or more, else 0 -- for short sequences a 64-row tile is most of the matrix, and filling it twice costs
+ * more than keeping the direction bits.  Same records either way. */
+#define SA_LONG_CHECKPOINT_AUTO 0xFFFFFFFFu
 int sa_set_long_checkpoint_rows(sa_ctx* ctx, uint32_t rows);
 /* Sequences longer than 64 residues, few pairs: a submission of at most 384 pairs per CU runs on a kernel that gives
  * every pair a whole wave (the 64 lanes sweep anti-diagonals of one matrix and hand their operands to the neighbour

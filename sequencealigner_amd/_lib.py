@@ -328,7 +328,10 @@ class Aligner:
         _check(self._lib.sa_set_cooperative_waves(self._ctx, waves))
 
     def set_long_checkpoint_rows(self, rows):
-        """Packed long-sequence kernel: 64 (default) or 32 rows between checkpoints, 0 = whole direction matrix."""
+        """Packed long-sequence kernel: 64 or 32 rows between checkpoints, 0 = whole direction matrix, None = the
+        library's choice (the default: 64 from a longest sequence of 512 residues, else 0)."""
+        if rows is None:
+            rows = 0xFFFFFFFF
         _check(self._lib.sa_set_long_checkpoint_rows(self._ctx, rows))
 
     def set_bucket_width(self, width):

@@ -141,7 +141,8 @@ struct sa_ctx {
     std::vector<uint64_t> cp, cq;      // prefix arrays of the packed record sizes (sa_compact.hip), built with the upload
     DevBuf d_cp, d_cq;
     bool compact_on_device = false;
-    uint32_t ckpt_rows = 64;           // paired long-sequence kernel: rows between checkpoints (32 or 64); 0 = the kernel that stores a whole direction matrix
+    uint32_t ckpt_rows = 64;           // paired long-sequence kernel in use: rows between checkpoints (32 or 64); 0 = the kernel that stores a whole direction matrix
+    bool ckpt_auto = true;             // ckpt_rows follows the longest uploaded sequence (sa_upload) until sa_set_long_checkpoint_rows names a value
     uint32_t bucket_width_forced = 0;  // sa_set_bucket_width: 0 = from the number of sequences per length
     // sequences (host mirror)
     uint64_t nseq = 0;
@@ -456,6 +457,12 @@ uint32_t coop_kib_per_wg(const sa_ctx* c) {
     const uint64_t bytes = (uint64_t)(c->lslot / 64) * (steps_cap / 16) * 256 + 2 * steps_cap * 4 + 2 * (c->lslot + 64) * 2;
     return (uint32_t)((bytes + 1023) / 1024);
 }
+
+// Which packed long-sequence kernel, left to the library: the checkpointing kernel fills again a 64-row tile per strip
+// and path, which for short sequences is most of the matrix; keeping two direction bits per cell is then cheaper.
+// All-vs-all sets, TCUPS checkpointing / direction rows: lengths 65-128 4.5 / 5.4, 100-300 6.7 / 7.2, 200-500 9.4 / 9.7,
+// 600-1400 16.2 / 10.6, 1500-3000 13.8 / 5.0 (tools/midlen_time.py).
+uint32_t long_auto_checkpoint_rows(uint32_t longest) { return longest >= 512 ? 64u : 0u; }
 
 // rows of the checkpointing kernel's border columns and checkpoints: the longest uploaded sequence, rounded up to 64
 uint32_t long_ckpt_rows_cap(const sa_ctx* c) { return (c->max_seq + 63u) & ~63u; }
@@ -859,6 +866,7 @@ int sa_upload(sa_ctx* c, const uint8_t* codes, const uint64_t* offs, const uint3
     const bool lng = lmax > SA_LP;
     const uint32_t lslot = lng ? (lmax + 63u) / 64u * 64u : SA_LP;
     c->spill_grid = 0;                            // scratch areas are sized by the slot and the longest sequence
+    if (c->ckpt_auto) c->ckpt_rows = long_auto_checkpoint_rows(lmax);
     c->lslot = lslot;
     c->row_bytes = lng ? 2 : 1;
     c->stride = lng ? (SA_LONG_HEADER_BYTES + 2 * lmax + 15u) & ~15u : (SA_REC_HEADER_BYTES + lmax + 15u) & ~15u;
@@ -969,6 +977,8 @@ int sa_clone_sequences(sa_ctx* dst, sa_ctx* src) {
     if (src->nseq == 0 || dst->inflight || src->max_seq > dst->max_len) return SA_ERR_STATE;
     if ((dst->device == SA_DEVICE_NONE) != (src->device == SA_DEVICE_NONE)) return SA_ERR_ARG;
     dst->nseq = src->nseq; dst->min_seq = src->min_seq; dst->max_seq = src->max_seq;
+    if (dst->ckpt_auto) dst->ckpt_rows = long_auto_checkpoint_rows(dst->max_seq);
+    dst->spill_grid = 0;
     dst->spill_grid = 0;
     dst->lslot = src->lslot; dst->row_bytes = src->row_bytes; dst->stride = src->stride;
     dst->len = src->len; dst->len_suffix = src->len_suffix; dst->slots_host = src->slots_host;
@@ -1370,13 +1380,14 @@ uint64_t sa_compact_bytes(const sa_ctx* c, int schedule, uint64_t r0, uint64_t r
 }
 
 int sa_set_long_checkpoint_rows(sa_ctx* c, uint32_t rows) {
-    if (!c || (rows != 0 && rows != 32 && rows != 64)) return SA_ERR_ARG;
+    if (!c || (rows != 0 && rows != 32 && rows != 64 && rows != SA_LONG_CHECKPOINT_AUTO)) return SA_ERR_ARG;
     if (c->inflight) return SA_ERR_STATE;
     if (c->device != SA_DEVICE_NONE) {
         SA_HIP_TRY(hipSetDevice(c->device));
         SA_HIP_TRY(hipStreamSynchronize(c->compute));
     }
-    c->ckpt_rows = rows;
+    c->ckpt_auto = rows == SA_LONG_CHECKPOINT_AUTO;
+    c->ckpt_rows = c->ckpt_auto ? long_auto_checkpoint_rows(c->max_seq) : rows;
     c->spill_grid = 0;             // the scratch areas are laid out per kernel
     c->resident_ready = false;
     return SA_OK;

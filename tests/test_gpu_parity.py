@@ -509,9 +509,10 @@ def test_long_paired_and_unpaired_kernels_give_identical_records(n, lo, hi, seed
     al.set_cooperative(-1)
     assert any(it[5] != 0xFFFFFFFF for it in al.work_items(sa.TRIANGULAR, 0, n - 1).tolist())
     paired = al.align(sa.TRIANGULAR)
-    assert al.last_kernel() == "sa_long_ckpt_kernel<64, 64>"
-    # the packed kernel's other forms: a checkpoint every 32 rows; two direction bits stored for every cell
-    for rows, kernel in ((32, "sa_long_ckpt_kernel<32, 64>"), (0, "sa_long_pair_kernel<4>")):
+    # left to itself the library takes the checkpointing kernel from a longest sequence of 512 residues
+    assert al.last_kernel() == ("sa_long_ckpt_kernel<64, 64>" if max(len(s) for s in seqs) >= 512 else "sa_long_pair_kernel<4>")
+    # the packed kernel's forms by name: checkpoints every 64 or 32 rows; two direction bits stored for every cell
+    for rows, kernel in ((64, "sa_long_ckpt_kernel<64, 64>"), (32, "sa_long_ckpt_kernel<32, 64>"), (0, "sa_long_pair_kernel<4>")):
         al.set_long_checkpoint_rows(rows)
         assert np.array_equal(al.align(sa.TRIANGULAR), paired), rows
         assert al.last_kernel() == kernel
@@ -899,8 +900,11 @@ def test_library_names_the_kernel_it_ran():
     assert bl.last_kernel() == "sa_coop_kernel"          # 3160 pairs: fewer than 384 per CU
     bl.set_cooperative(-1)
     bl.align(sa.TRIANGULAR)
+    assert bl.last_kernel() == "sa_long_pair_kernel<4>"       # longest sequence below 512 residues: direction rows kept
+    bl.set_long_checkpoint_rows(64)
+    bl.align(sa.TRIANGULAR)
     assert bl.last_kernel() == "sa_long_ckpt_kernel<64, 64>"
-    bl.set_long_checkpoint_rows(0)
+    bl.set_long_checkpoint_rows(None)
     bl.align(sa.TRIANGULAR)
     assert bl.last_kernel() == "sa_long_pair_kernel<4>"
     bl.align(sa.ADJACENT)

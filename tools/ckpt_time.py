@@ -6,8 +6,10 @@ from sequencealigner_amd import synth
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 cks = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 32, 64]
-seqs, _ = synth.generate(n, 300, 1000, 2)
-al = sa.Aligner(max_seq_len=1000)
+import os
+lo, hi = int(os.environ.get("SA_LEN_LO", 300)), int(os.environ.get("SA_LEN_HI", 1000))
+seqs, _ = synth.generate(n, lo, hi, 2)
+al = sa.Aligner(max_seq_len=hi)
 al.upload(seqs)
 import os
 if os.environ.get("SA_WG_PER_CU"):
