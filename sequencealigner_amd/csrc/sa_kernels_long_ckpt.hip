@@ -525,7 +525,7 @@ __global__ void __launch_bounds__(64, 4) sa_long_ckpt_kernel(const SaPepParams P
                  : [vo] "v"(voff), [a0] "s"(tile_a + (size_t)(CH) * 8192), [a1] "s"(tile_a + (size_t)(CH) * 8192 + 4096), \
                    [b0] "s"(tile_b + (size_t)(CH) * 8192), [b1] "s"(tile_b + (size_t)(CH) * 8192 + 4096),                 \
                    [rp] "v"(resp + 8 * (CH)), [na] "s"(needA_), [nb] "s"(needB_)                                          \
-                 : "memory");                                                                                            \
+                 : "memory", "scc");                                                                                     \
     }
 #define SA_LCK_STEP(H, TC, D, REC)                                                                                         \
     if ((TC) == t) {                                                                                                       \
