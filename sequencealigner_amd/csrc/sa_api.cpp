@@ -934,11 +934,17 @@ uint64_t sa_pair_count(const sa_ctx* c, int schedule, uint64_t r0, uint64_t r1) 
 
 uint64_t sa_cell_count(const sa_ctx* c, int schedule, uint64_t r0, uint64_t r1) {
     if (!c || r1 <= r0) return 0;
+    std::vector<uint64_t> part(sa_host_threads(), 0);
+    sa_parallel_for(r1 - r0, 1 << 18, [&](uint64_t lo, uint64_t hi, unsigned t) {
+        uint64_t cells = 0;
+        for (uint64_t i = r0 + lo; i < r0 + hi; i++) {
+            if (schedule == SA_SCHEDULE_ADJACENT) cells += (uint64_t)c->len[i] * c->len[i + 1];
+            else cells += (uint64_t)c->len[i] * c->len_suffix[i + 1];
+        }
+        part[t] = cells;
+    });
     uint64_t cells = 0;
-    for (uint64_t i = r0; i < r1; i++) {
-        if (schedule == SA_SCHEDULE_ADJACENT) cells += (uint64_t)c->len[i] * c->len[i + 1];
-        else cells += (uint64_t)c->len[i] * c->len_suffix[i + 1];
-    }
+    for (uint64_t a : part) cells += a;
     return cells;
 }
 

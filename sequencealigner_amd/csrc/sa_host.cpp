@@ -493,19 +493,36 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
     if (!offs_mem || !lens_mem) { err = "out of memory"; cleanup(); if (out_fd >= 0) close(out_fd); return fail(SA_ERR_NOMEM); }
     uint64_t* const offs = offs_mem.get();
     uint32_t* const lens = lens_mem.get();
-    uint64_t total = 0;
     uint32_t longest_seq = 0, longest_other = 0;     // what the row buffers of the host formatter are sized by
-    for (uint64_t s = 0; s < n; s++) {
-        const Row& r = tab.rows[s];
-        longest_seq = std::max(longest_seq, r.len);
-        longest_other = std::max(longest_other, r.other_len);
-        if (r.len == 0 || r.len > max_len) {
-            err = "row " + std::to_string(s + 2) + ": sequence length " + std::to_string(r.len) + " outside 1.." + std::to_string(max_len);
+    {
+        // lengths, their range and the first row outside it, on the host threads; offsets as prefix sums
+        struct Part { uint32_t seq = 0, other = 0; uint64_t bad = UINT64_MAX; };
+        std::vector<Part> part(sa_host_threads());
+        sa_parallel_for(n, 1 << 16, [&](uint64_t lo, uint64_t hi, unsigned t) {
+            Part q;
+            for (uint64_t s = lo; s < hi; s++) {
+                const Row& r = tab.rows[s];
+                q.seq = std::max(q.seq, r.len);
+                q.other = std::max(q.other, r.other_len);
+                if ((r.len == 0 || r.len > max_len) && q.bad == UINT64_MAX) q.bad = s;
+                lens[s] = r.len;
+            }
+            part[t] = q;
+        });
+        uint64_t bad = UINT64_MAX;
+        for (const Part& q : part) {
+            longest_seq = std::max(longest_seq, q.seq);
+            longest_other = std::max(longest_other, q.other);
+            bad = std::min(bad, q.bad);
+        }
+        if (bad != UINT64_MAX) {
+            err = "row " + std::to_string(bad + 2) + ": sequence length " + std::to_string(tab.rows[bad].len) + " outside 1.." + std::to_string(max_len);
             cleanup(); if (out_fd >= 0) close(out_fd);
             return fail(SA_ERR_LENGTH);
         }
-        offs[s] = total; lens[s] = r.len; total += r.len;
+        prefix_sums(n, offs, [&](uint64_t s) { return (uint64_t)lens[s]; });
     }
+    const uint64_t total = n ? offs[n] : 0;
     std::unique_ptr<uint8_t[]> codes_mem(new (std::nothrow) uint8_t[total + 1]);
     if (!codes_mem) { err = "out of memory"; cleanup(); if (out_fd >= 0) close(out_fd); return fail(SA_ERR_NOMEM); }
     uint8_t* const codes = codes_mem.get();
@@ -537,8 +554,21 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
         int ndev = st->num_devices;
         {
             double cells = 0;
-            if (schedule == SA_SCHEDULE_ADJACENT) for (uint64_t s = 0; s + 1 < n; s++) cells += (double)lens[s] * lens[s + 1];
-            else { double suffix = 0; for (uint64_t s = n; s-- > 0;) { cells += (double)lens[s] * suffix; suffix += lens[s]; } }
+            if (schedule == SA_SCHEDULE_ADJACENT) {
+                std::vector<double> part(sa_host_threads(), 0.0);
+                sa_parallel_for(n - 1, 1 << 16, [&](uint64_t lo, uint64_t hi, unsigned t) {
+                    double a = 0;
+                    for (uint64_t s = lo; s < hi; s++) a += (double)lens[s] * lens[s + 1];
+                    part[t] = a;
+                });
+                for (double a : part) cells += a;
+            } else {
+                // sum over i < j of len[i] len[j] = ((sum len)^2 - sum len^2) / 2
+                const double sum = (double)total;
+                double sq = 0;
+                for (uint64_t s = 0; s < n; s++) sq += (double)lens[s] * lens[s];
+                cells = (sum * sum - sq) / 2;
+            }
             const double est_ms = cells / (schedule == SA_SCHEDULE_ADJACENT ? 2e12 : 8e12) * 1e3;
             if (!st->force_devices) ndev = std::max(1, std::min(ndev, (int)(est_ms / 30.0)));
         }
