@@ -147,7 +147,8 @@ struct sa_ctx {
     // sequences (host mirror)
     uint64_t nseq = 0;
     std::vector<uint16_t> len;         // file order
-    std::vector<uint64_t> len_suffix;  // len_suffix[i] = sum of len[i..]; built on first TRIANGULAR use
+    std::vector<uint64_t> len_suffix;  // len_suffix[i] = sum of len[i..]; built on first TRIANGULAR use (ensure_suffix)
+    std::mutex tables_mu;              // the lazily built host tables (len_suffix, cp, cq): a const context may be asked from any thread
     std::vector<uint8_t> slots_host;   // file-order slots: host-only contexts, or read back from the device for the bucket order
     uint32_t min_seq = 0, max_seq = 0; // shortest / longest uploaded sequence
     uint32_t stride = 80;
@@ -200,8 +201,13 @@ bool packed_cells_fit(const sa_ctx* c, bool lng) {
     return span * c->sprime_max <= 1983;
 }
 
+// Tables with one 8-byte entry per sequence are built when something first asks for them, under a lock (queries take
+// a const context and may come from any thread): the 4 001 280-row ADJACENT run with rows written on the device needs
+// none of them, and their 96 MB of fresh pages were 20 ms of its upload.
 // len_suffix[i] = sum of len[i ..]
-void ensure_suffix(sa_ctx* c) {
+void ensure_suffix(const sa_ctx* cc) {
+    sa_ctx* c = const_cast<sa_ctx*>(cc);
+    std::lock_guard<std::mutex> lock(c->tables_mu);
     const uint64_t n = c->nseq;
     if (c->len_suffix.size() == n + 1) return;
     c->len_suffix.resize(n + 1);
@@ -220,8 +226,11 @@ inline uint32_t packed_record_bytes(const sa_ctx* c, uint32_t len) {
 }
 // cp[s] = packed bytes of the records whose second sequence is one of 0 .. s-1; cq[i] = packed bytes of the
 // TRIANGULAR rows of first sequences 0 .. i-1 (row i holds second sequences i+1 .. n-1)
-void build_compact_tables(sa_ctx* c) {
+void ensure_compact_tables(const sa_ctx* cc) {
+    sa_ctx* c = const_cast<sa_ctx*>(cc);
+    std::lock_guard<std::mutex> lock(c->tables_mu);
     const uint64_t n = c->nseq;
+    if (c->cp.size() == n + 2 && c->cq.size() == n + 1) return;
     c->cp.resize(n + 2);
     prefix_sums(n, c->cp.data(), [&](uint64_t s) { return (uint64_t)packed_record_bytes(c, c->len[s]); });
     c->cp[n + 1] = c->cp[n];
@@ -232,6 +241,7 @@ void build_compact_tables(sa_ctx* c) {
 }
 int ensure_compact_on_device(sa_ctx* c) {
     if (c->compact_on_device) return SA_OK;
+    ensure_compact_tables(c);
     int rc;
     if ((rc = c->d_cp.reserve(c->cp.size() * 8)) || (rc = c->d_cq.reserve(c->cq.size() * 8))) return rc;
     SA_HIP_TRY(hipMemcpy(c->d_cp.p, c->cp.data(), c->cp.size() * 8, hipMemcpyHostToDevice));
@@ -878,9 +888,11 @@ int sa_upload(sa_ctx* c, const uint8_t* codes, const uint64_t* offs, const uint3
     sa_parallel_for(nseq, 1 << 16, [&](uint64_t lo, uint64_t hi, unsigned) {
         for (uint64_t s = lo; s < hi; s++) c->len[s] = (uint16_t)lens[s];
     });
-    c->len_suffix.clear();
-    ensure_suffix(c);      // here, not lazily: sa_cell_count / sa_shard_rows take a const context and may run on any thread
-    build_compact_tables(c);
+    {
+        std::lock_guard<std::mutex> lock(c->tables_mu);     // rebuilt for the new sequences when first asked for
+        c->len_suffix.clear(); c->cp.clear(); c->cq.clear();
+        c->compact_on_device = false;
+    }
     if (c->device == SA_DEVICE_NONE) {
         // no device to read the slots back from: a host-only context keeps them itself
         c->slots_host.assign((size_t)(nseq + 2) * lslot, SA_PAD_CODE);
@@ -934,6 +946,7 @@ uint64_t sa_pair_count(const sa_ctx* c, int schedule, uint64_t r0, uint64_t r1) 
 
 uint64_t sa_cell_count(const sa_ctx* c, int schedule, uint64_t r0, uint64_t r1) {
     if (!c || r1 <= r0) return 0;
+    if (schedule != SA_SCHEDULE_ADJACENT) ensure_suffix(c);
     std::vector<uint64_t> part(sa_host_threads(), 0);
     sa_parallel_for(r1 - r0, 1 << 18, [&](uint64_t lo, uint64_t hi, unsigned t) {
         uint64_t cells = 0;
@@ -954,7 +967,7 @@ uint32_t sa_record_row_bytes(const sa_ctx* c) { return c ? c->row_bytes : 0; }
 int sa_shard_rows(const sa_ctx* c, int schedule, uint32_t parts, uint64_t* bounds) {
     if (!c || !bounds || parts == 0) return SA_ERR_ARG;
     const uint64_t rows = sa_schedule_rows(c, schedule);
-    const uint64_t total = sa_cell_count(c, schedule, 0, rows);
+    const uint64_t total = sa_cell_count(c, schedule, 0, rows);      // builds the suffix sums a TRIANGULAR split needs
     uint64_t acc = 0, row = 0;
     bounds[0] = 0;
     for (uint32_t k = 1; k < parts; k++) {
@@ -985,10 +998,14 @@ int sa_clone_sequences(sa_ctx* dst, sa_ctx* src) {
     dst->nseq = src->nseq; dst->min_seq = src->min_seq; dst->max_seq = src->max_seq;
     if (dst->ckpt_auto) dst->ckpt_rows = long_auto_checkpoint_rows(dst->max_seq);
     dst->spill_grid = 0;
-    dst->spill_grid = 0;
     dst->lslot = src->lslot; dst->row_bytes = src->row_bytes; dst->stride = src->stride;
-    dst->len = src->len; dst->len_suffix = src->len_suffix; dst->slots_host = src->slots_host;
-    dst->cp = src->cp; dst->cq = src->cq; dst->compact_on_device = false;
+    dst->len = src->len; dst->slots_host = src->slots_host;
+    {
+        std::lock_guard<std::mutex> lock_dst(dst->tables_mu);
+        std::lock_guard<std::mutex> lock_src(src->tables_mu);
+        dst->len_suffix = src->len_suffix; dst->cp = src->cp; dst->cq = src->cq;      // as far as the donor has built them
+        dst->compact_on_device = false;
+    }
     dst->resident_ready = false;
     dst->tri_ready = false;
     const bool dev = dst->device != SA_DEVICE_NONE;
@@ -1375,13 +1392,15 @@ uint32_t sa_compact_record_size(const sa_ctx* c, uint64_t second_sequence) {
 }
 
 uint64_t sa_compact_pair_offset(const sa_ctx* c, int schedule, uint64_t i, uint64_t j) {
-    if (!c || i >= j || j >= c->nseq || c->cp.size() != c->nseq + 2) return 0;
+    if (!c || i >= j || j >= c->nseq) return 0;
     if (schedule == SA_SCHEDULE_ADJACENT && j != i + 1) return 0;
+    ensure_compact_tables(c);
     return compact_offset(c, schedule, i, j);
 }
 
 uint64_t sa_compact_bytes(const sa_ctx* c, int schedule, uint64_t r0, uint64_t r1) {
-    if (!c || r1 <= r0 || r1 > sa_schedule_rows(c, schedule) || c->cp.size() != c->nseq + 2) return 0;
+    if (!c || r1 <= r0 || r1 > sa_schedule_rows(c, schedule)) return 0;
+    ensure_compact_tables(c);
     return schedule == SA_SCHEDULE_ADJACENT ? c->cp[r1 + 1] - c->cp[r0 + 1] : c->cq[r1] - c->cq[r0];
 }
 
