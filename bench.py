@@ -389,7 +389,7 @@ def e2e_mega(sa, mega_path, out_dir, device):
             st.devices[k] = device
         dst = os.path.join(out_dir, f"mega_out_{ndev}.csv")
         best = None
-        for _ in range(2):
+        for _ in range(3):
             rep = sa.run_csv(mega_path, dst, sa.ADJACENT, settings=st)
             if best is None or rep.seconds < best.seconds:
                 best = rep
@@ -431,7 +431,7 @@ def e2e_mega(sa, mega_path, out_dir, device):
         st.force_devices = forced
         for k in range(ndev):
             st.devices[k] = device
-        rep = min((sa.run_csv(mega_path, None, sa.ADJACENT, settings=st) for _ in range(2)), key=lambda r: r.seconds)
+        rep = min((sa.run_csv(mega_path, None, sa.ADJACENT, settings=st) for _ in range(5)), key=lambda r: r.seconds)
         key = "without_write" if ndev == 1 else "without_write_contexts_3" + ("_forced" if forced else "")
         out[key] = {"devices_used": rep.devices_used, "seconds": round(rep.seconds, 4),
                     "pairs_per_s": round(rep.pairs / rep.seconds, 1), "gcups": round(rep.cells / rep.seconds / 1e9, 2)}
