@@ -195,9 +195,21 @@ void table_range(const int32_t* S, int32_t gap, int64_t& low, int64_t& top) {
         low = std::min(low, sp); top = std::max(top, sp);
     }
 }
+// Packed 16-bit cells hold 16 (D - base) + two tag fields below 0x7c00: D - base <= 1983.  Peptides: base 0, D grows
+// by at most max S' per row and column, so longest sequence x max S' must fit.  Long sequences: a strip is 64 columns
+// wide and the lanes' bases move up to the row above every R rows, so (64 + R + 1) x max S' must fit; R = 16 where
+// the table allows it (max S' <= 24: BLOSUM50 at gap -4), else 8 (<= 27) or 4 (<= 28) -- a move of the bases is 64
+// subtractions per lane, 2.6 % of the tagged rows' instructions at R = 8.  0: the table does not fit.
+uint32_t long_rebase_rows(const sa_ctx* c) {
+    if (c->sprime_min < 1) return 0;
+    for (uint32_t rows : {16u, 8u, 4u})
+        if ((int64_t)(64 + rows + 1) * c->sprime_max <= 1983) return rows;
+    return 0;
+}
 bool packed_cells_fit(const sa_ctx* c, bool lng) {
     if (c->sprime_min < 1) return false;
-    const int64_t span = lng ? 17 + 64 : std::max<int64_t>(1, std::min<int64_t>(c->max_seq, SA_LP));
+    if (lng) return long_rebase_rows(c) != 0;
+    const int64_t span = std::max<int64_t>(1, std::min<int64_t>(c->max_seq, SA_LP));
     return span * c->sprime_max <= 1983;
 }
 
@@ -576,6 +588,7 @@ int launch_work(sa_ctx* c, Work& w, bool timed) {
     if (timed) SA_HIP_TRY(hipEventRecord(w.t0, c->compute));
     P.lslot = c->lslot;
     P.bcol = (int32_t*)c->d_bcol.p;
+    P.rebase_mask = std::max<uint32_t>(long_rebase_rows(c), 4) - 1;
     const bool tri = w.schedule == SA_SCHEDULE_TRIANGULAR;
     if (w.coop) {
         const int waves = coop_waves_for(c, w.nitems);

@@ -108,6 +108,8 @@ typedef struct {
     /* long-sequence kernel only */
     uint32_t lslot;              /* bytes per file-order slot = rows of codes_t = row capacity (multiple of 64) */
     int32_t* bcol;               /* per workgroup 2 x lslot x 64: last DP column of a strip, for the next strip */
+    uint32_t rebase_mask;        /* packed long kernels, tagged rows: the lanes' bases move up every rebase_mask + 1 rows
+                                    (15, 7 or 3: the larger the table's entries, the more often) */
 } SaPepParams;
 
 

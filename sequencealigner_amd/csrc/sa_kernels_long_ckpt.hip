@@ -464,7 +464,7 @@ __global__ void __launch_bounds__(64, 4) sa_long_ckpt_kernel(const SaPepParams P
                         const uint32_t nres = residues4(r0 + t + 4);
                         const uint4 nbord = border4(r0 + t + 4);
                         const uint32_t rb0 = bres & 0xff, rb1 = (bres >> 8) & 0xff, rb2 = (bres >> 16) & 0xff, rb3 = bres >> 24;
-                        if ((t & 15) == 0 && t > 0 && !first_strip) {
+                        if ((t & (int)P.rebase_mask) == 0 && t > 0 && !first_strip) {
                             // move the bases up to the border of the row above; the register row follows
                             const uint32_t dd = lck_pk_shl4(lck_pk_sub(prevw, base12));
 #pragma unroll

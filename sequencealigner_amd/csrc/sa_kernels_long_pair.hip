@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_pair_kernel(const 
                     const uint32_t nres = residues4(r + 4);
                     const uint4 nbord = border4(r + 4);
                     const uint32_t rb0 = bres & 0xff, rb1 = (bres >> 8) & 0xff, rb2 = (bres >> 16) & 0xff, rb3 = bres >> 24;
-                    if ((r & 15) == 0 && r > 0 && !first_strip) {
+                    if ((r & (int)P.rebase_mask) == 0 && r > 0 && !first_strip) {
                         // move the bases up to the border of the row above; the register row follows
                         const uint32_t d = sa_pk_sub_u16(prevw, base12);
                         const uint32_t dd = sa_pk_shl4_u16(d);

@@ -171,6 +171,44 @@ def test_longest_supported_sequences():
         _check_pairs(al, rec, [(k, k + 1) for k in range(len(seqs) - 1)])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("gap,top,rows_between_rebases", [(-5, 15, 8), (-6, 15, 8), (-6, 16, 4), (-7, 15, None)])
+def test_packed_long_kernels_at_the_edge_of_their_table_range(gap, top, rows_between_rebases):
+    """Tagged 16-bit cells hold 16 (D - base) below 0x7c00; a long strip is 64 columns wide and the bases move every 16, 8
+    or 4 rows, the more often the larger the table's entries: shifted scores up to 24, 27, 28.  Runs of one letter whose
+    self-score is the table's largest entry make D grow by that much per step; beyond 28 the 32-bit kernel runs."""
+    rng = random.Random(31 + top - gap)
+    matrix = [rng.randint(-3, 6) for _ in range(400)]
+    for a in range(20):
+        for b in range(a):
+            matrix[a * 20 + b] = matrix[b * 20 + a]
+    w = ALPHABET.index("W")
+    matrix[w * 20 + w] = top                       # S' = top - 2 gap
+    seqs = ["W" * 700, "W" * 650 + "A" * 30, "W" * 513, "C" * 40 + "W" * 600, "".join(rng.choice("WA") for _ in range(600)),
+            "W" * 300 + "".join(rng.choice(ALPHABET) for _ in range(300))]
+    seqs += ["".join(rng.choice(ALPHABET) for _ in range(rng.randint(65, 700))) for _ in range(70)]
+    n = len(seqs)
+    al = sa.Aligner(gap=gap, matrix=matrix, max_seq_len=700)
+    al.set_cooperative(-1)
+    al.upload(seqs)
+    ref = None
+    for rows in (64, 0):
+        al.set_long_checkpoint_rows(rows)
+        rec = al.align(sa.TRIANGULAR)
+        if rows_between_rebases is None:
+            assert al.last_kernel() == "sa_long_kernel<0, 2>"          # the table does not fit packed cells
+        else:
+            assert al.last_kernel() == ("sa_long_ckpt_kernel<64, 64>" if rows else "sa_long_pair_kernel<4>")
+        if ref is None:
+            ref = rec
+            _check_pairs(al, rec[: n - 1], [(0, j) for j in range(1, n)], gap=gap, matrix=matrix)
+        else:
+            assert np.array_equal(rec, ref), rows
+    al.set_pairing(False)
+    assert np.array_equal(al.align(sa.TRIANGULAR), ref)
+    assert al.last_kernel() == "sa_long_kernel<0, 2>"
+
+
 def test_long_sequences_whose_matrix_values_pass_16_bits():
     """Near-identical sequences of 4096 residues: D reaches 4096 * 23 = 94 208 with the default table, so the strip
     border columns, which the packed long kernel hands from strip to strip as the low 16 bits of the values, wrap
@@ -536,15 +574,16 @@ def test_long_paired_and_unpaired_kernels_give_identical_records(n, lo, hi, seed
 
 @pytest.mark.gpu
 def test_long_paired_kernel_at_the_edge_of_its_range():
-    """S - 2*gap up to 24 is the most the long paired kernel takes (registers hold at most 16 * 81 * 24 + 15,
-    below the first half-precision pattern that is not a finite number); one more and the library must use
-    32-bit cells by itself.  Sequences of one letter reach the largest D.  At the lower edge (1 for a mismatch)
-    the candidates tie all the time; with 0 the 32-bit cells take over."""
+    """S - 2*gap up to 28 is the most the long paired kernels take (registers hold at most 16 * 81 * 24 + 15 with the
+    bases moved every 16 rows, 16 * 69 * 28 + 15 with every 4: below the first half-precision pattern that is not a
+    finite number); one more and the library must use 32-bit cells by itself.  Sequences of one letter reach the
+    largest D.  At the lower edge (1 for a mismatch) the candidates tie all the time; with 0 the 32-bit cells take
+    over."""
     rng = random.Random(9)
     seqs = ["".join(rng.choice("AAAR") for _ in range(rng.choice([400, 333, 256, 129]))) for _ in range(70)]
     n = len(seqs)
     # (match score, lowest mismatch score): S' = score + 8
-    for top, worst, expect_pairs in ((16, 13, True), (17, 14, False), (16, -7, True), (16, -8, False)):
+    for top, worst, expect_pairs in ((16, 13, True), (17, 14, True), (20, 17, True), (21, 18, False), (16, -7, True), (16, -8, False)):
         matrix = [top if a == b else worst + rng.randint(0, 3) for a in range(20) for b in range(20)]
         matrix[1] = matrix[20] = worst          # A/R, the two letters in use
         al = sa.Aligner(gap=-4, matrix=matrix, max_seq_len=400)
