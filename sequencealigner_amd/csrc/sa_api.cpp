@@ -27,8 +27,8 @@ extern "C" void sa_launch_digest(const void* records, uint64_t bytes, unsigned l
 extern "C" void sa_launch_peptide_pair(int ng, const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream);
 extern "C" size_t sa_format_scan_bytes(uint64_t n);
 extern "C" hipError_t sa_launch_format(const SaFormatParams* F, void* scan_tmp, size_t scan_bytes, hipStream_t stream);
-extern "C" void sa_launch_long_pair(const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream);
-extern "C" void sa_launch_long_ckpt(int ck_rows, const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream);
+extern "C" void sa_launch_long_pair(int wide, const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream);
+extern "C" void sa_launch_long_ckpt(int ck_rows, int wide, const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream);
 extern "C" void sa_launch_coop(const SaPepParams* p, unsigned grid, hipStream_t stream);
 extern "C" void sa_launch_coop_wg(int waves, const SaPepParams* p, unsigned grid, hipStream_t stream);
 extern "C" unsigned sa_coop_wg_lds_bytes(unsigned lslot, int waves);
@@ -195,23 +195,29 @@ void table_range(const int32_t* S, int32_t gap, int64_t& low, int64_t& top) {
         low = std::min(low, sp); top = std::max(top, sp);
     }
 }
-// Packed 16-bit cells hold 16 (D - base) + two tag fields below 0x7c00: D - base <= 1983.  Peptides: base 0, D grows
-// by at most max S' per row and column, so longest sequence x max S' must fit.  Long sequences: a strip is 64 columns
-// wide and the lanes' bases move up to the row above every R rows, so (64 + R + 1) x max S' must fit; R = 16 where
-// the table allows it (max S' <= 24: BLOSUM50 at gap -4), else 8 (<= 27) or 4 (<= 28) -- a move of the bases is 64
-// subtractions per lane, 2.6 % of the tagged rows' instructions at R = 8.  0: the table does not fit.
-uint32_t long_rebase_rows(const sa_ctx* c) {
+// Packed 16-bit cells hold 16 (D - base) + two tag fields.  With the three-way maximum as one v_pk_maximum3_f16 the
+// patterns must stay below 0x7c00: D - base <= 1983 ("narrow").  With two v_pk_max_u16 per maximum (one instruction
+// more per column) the whole 16-bit range is usable: D - base <= 4095 ("wide"; long sequences only).
+// Peptides: base 0, D grows by at most max S' per row and column, so longest sequence x max S' must fit.  Long
+// sequences: a strip is 64 columns wide and the lanes' bases move up to the row above every R rows, so
+// (64 + R + 1) x max S' must fit; R = 16 where the table allows it, else 8 or 4 -- a move of the bases is 64
+// subtractions per lane, 2.6 % of the tagged rows' instructions at R = 8.  Narrow: max S' <= 24 (BLOSUM50 at gap -4:
+// 23), 27, 28; wide: <= 50, 56, 59.  0: the table does not fit.  Same table, same box, 2 000 proteins: narrow 68.0 ms,
+// wide 76.4 ms (checkpointing kernel), 88.7 / 95.9 ms (direction rows); the 32-bit kernel takes 146 ms.
+uint32_t long_rebase_rows(const sa_ctx* c, int64_t limit) {
     if (c->sprime_min < 1) return 0;
     for (uint32_t rows : {16u, 8u, 4u})
-        if ((int64_t)(64 + rows + 1) * c->sprime_max <= 1983) return rows;
+        if ((int64_t)(64 + rows + 1) * c->sprime_max <= limit) return rows;
     return 0;
 }
-bool packed_cells_fit(const sa_ctx* c, bool lng) {
-    if (c->sprime_min < 1) return false;
-    if (lng) return long_rebase_rows(c) != 0;
+enum { kCellsNone = 0, kCellsNarrow = 1, kCellsWide = 2 };
+int packed_cells_mode(const sa_ctx* c, bool lng) {
+    if (c->sprime_min < 1) return kCellsNone;
+    if (lng) return long_rebase_rows(c, 1983) ? kCellsNarrow : long_rebase_rows(c, 4095) ? kCellsWide : kCellsNone;
     const int64_t span = std::max<int64_t>(1, std::min<int64_t>(c->max_seq, SA_LP));
-    return span * c->sprime_max <= 1983;
+    return span * c->sprime_max <= 1983 ? kCellsNarrow : kCellsNone;
 }
+bool packed_cells_fit(const sa_ctx* c, bool lng) { return packed_cells_mode(c, lng) != kCellsNone; }
 
 // Tables with one 8-byte entry per sequence are built when something first asks for them, under a lock (queries take
 // a const context and may come from any thread): the 4 001 280-row ADJACENT run with rows written on the device needs
@@ -588,7 +594,8 @@ int launch_work(sa_ctx* c, Work& w, bool timed) {
     if (timed) SA_HIP_TRY(hipEventRecord(w.t0, c->compute));
     P.lslot = c->lslot;
     P.bcol = (int32_t*)c->d_bcol.p;
-    P.rebase_mask = std::max<uint32_t>(long_rebase_rows(c), 4) - 1;
+    const bool wide = is_long(c) && packed_cells_mode(c, true) == kCellsWide;
+    P.rebase_mask = std::max<uint32_t>(long_rebase_rows(c, wide ? 4095 : 1983), 4) - 1;
     const bool tri = w.schedule == SA_SCHEDULE_TRIANGULAR;
     if (w.coop) {
         const int waves = coop_waves_for(c, w.nitems);
@@ -609,12 +616,13 @@ int launch_work(sa_ctx* c, Work& w, bool timed) {
                            : waves == 8 ? "sa_coop_wg_kernel<8>" : "sa_coop_wg_kernel<16>";
         }
     } else if (ckpt) {
-        sa_launch_long_ckpt((int)c->ckpt_rows, &P, grid, SA_LDS_PROF_BYTES + 64 + 2 * c->lslot, c->compute);
-        c->last_kernel = c->ckpt_rows == 64 ? "sa_long_ckpt_kernel<64, 64>" : "sa_long_ckpt_kernel<32, 64>";
+        sa_launch_long_ckpt((int)c->ckpt_rows, wide ? 1 : 0, &P, grid, SA_LDS_PROF_BYTES + 64 + 2 * c->lslot, c->compute);
+        c->last_kernel = wide ? "sa_long_ckpt_wide_kernel<64, 64>"        // one form: a checkpoint every 64 rows
+                       : c->ckpt_rows == 64 ? "sa_long_ckpt_kernel<64, 64>" : "sa_long_ckpt_kernel<32, 64>";
     } else if (is_long(c) && tri && w.paired) {
         // + 64: rows read table entries two groups ahead, up to 16 bytes past the last profile row; + 2 lslot: the two first sequences
-        sa_launch_long_pair(&P, grid, SA_LDS_PROF_BYTES + 64 + 2 * c->lslot, c->compute);
-        c->last_kernel = "sa_long_pair_kernel<4>";
+        sa_launch_long_pair(wide ? 1 : 0, &P, grid, SA_LDS_PROF_BYTES + 64 + 2 * c->lslot, c->compute);
+        c->last_kernel = wide ? "sa_long_pair_wide_kernel<4>" : "sa_long_pair_kernel<4>";
     } else if (is_long(c)) {
         // + 64 as above; + lslot: copy of the shared first sequence
         sa_launch_long(tri ? 0 : 1, &P, grid, SA_LDS_PROF_BYTES + 64 + c->lslot, c->compute);

@@ -68,17 +68,32 @@ __device__ __forceinline__ uint32_t lck_pk_shl4(uint32_t a) {     // each half s
     NEXT_DIAG                                                        \
     "v_pk_maximum3_f16 %[b2], %[ma1], %[b2], %[b1]\n\t"              \
     "v_pk_maximum3_f16 %[b3], %[mb1], %[b3], %[b2]"
+// the same with every three-way maximum as two unsigned 16-bit maxima (tables whose values leave the range of the
+// half-precision patterns: three instructions per column instead of two)
+#define SA_SC_ADDS_MAXS_WIDE(NEXT_DIAG)                              \
+    "v_add_u32 %[mb0], %[b0], %[sx]\n\t"                             \
+    "v_add_u32 %[ma1], %[b1], %[sy]\n\t"                             \
+    "v_pk_max_u16 %[b0], %[ma], %[b0]\n\t"                           \
+    "v_pk_max_u16 %[b0], %[b0], %[zl]\n\t"                           \
+    "v_add_u32 %[mb1], %[b2], %[sz]\n\t"                             \
+    "v_pk_max_u16 %[b1], %[mb0], %[b1]\n\t"                          \
+    "v_pk_max_u16 %[b1], %[b1], %[b0]\n\t"                           \
+    NEXT_DIAG                                                        \
+    "v_pk_max_u16 %[b2], %[ma1], %[b2]\n\t"                          \
+    "v_pk_max_u16 %[b2], %[b2], %[b1]\n\t"                           \
+    "v_pk_max_u16 %[b3], %[mb1], %[b3]\n\t"                          \
+    "v_pk_max_u16 %[b3], %[b3], %[b2]"
 // four columns 4G .. 4G+3 with the table entries SC (x .. w = columns 4G+1 .. 4G+4)
-#define SA_SC_GROUP(G, SC)                                                                          \
+#define SA_SC_GROUP_FORM(TEXT, G, SC)                                                               \
     {                                                                                               \
         uint32_t mb0_, ma1_, mb1_;                                                                  \
         if ((G) == SA_LP / 4 - 1) {                                                                 \
-            asm volatile(SA_SC_ADDS_MAXS("")                                                        \
+            asm volatile(TEXT("")                                                                   \
                          : [b0] "+v"(B[4 * (G)]), [b1] "+v"(B[4 * (G) + 1]), [b2] "+v"(B[4 * (G) + 2]),       \
                            [b3] "+v"(B[4 * (G) + 3]), [mb0] "=&v"(mb0_), [ma1] "=&v"(ma1_), [mb1] "=&v"(mb1_) \
                          : [ma] "v"(ma_), [sx] "v"(SC.x), [sy] "v"(SC.y), [sz] "v"(SC.z), [zl] "v"(B[4 * (G) - 1]));     \
         } else {                                                                                    \
-            asm volatile(SA_SC_ADDS_MAXS("v_add_u32 %[ma], %[b3], %[sw]\n\t")                       \
+            asm volatile(TEXT("v_add_u32 %[ma], %[b3], %[sw]\n\t")                                  \
                          : [b0] "+v"(B[4 * (G)]), [b1] "+v"(B[4 * (G) + 1]), [b2] "+v"(B[4 * (G) + 2]),       \
                            [b3] "+v"(B[4 * (G) + 3]), [mb0] "=&v"(mb0_), [ma1] "=&v"(ma1_), [mb1] "=&v"(mb1_), \
                            [ma] "+v"(ma_)                                                           \
@@ -86,6 +101,9 @@ __device__ __forceinline__ uint32_t lck_pk_shl4(uint32_t a) {     // each half s
                            [zl] "v"((G) == 0 ? left0 : B[(G) == 0 ? 0 : 4 * (G) - 1]));                  \
         }                                                                                           \
     }
+#define SA_SC_GROUP(G, SC)                                                                          \
+    if constexpr (WIDE) SA_SC_GROUP_FORM(SA_SC_ADDS_MAXS_WIDE, G, SC)                               \
+    else SA_SC_GROUP_FORM(SA_SC_ADDS_MAXS, G, SC)
 typedef int sa_i32x4v __attribute__((ext_vector_type(4)));
 typedef uint32_t sa_u32x4v __attribute__((ext_vector_type(4)));
 typedef uint32_t sa_u32x2v __attribute__((ext_vector_type(2)));
@@ -127,7 +145,7 @@ typedef uint32_t sa_u32x2v __attribute__((ext_vector_type(2)));
         }                                                                                           \
     }
 
-template <bool FULL>
+template <bool FULL, bool WIDE = false>
 __device__ __forceinline__ void fill_row_score(uint32_t (&B)[SA_LP], const int oend, const uint32_t diag0,
                                                const uint32_t left0, const int32_t* __restrict__ row_base) {
     const uint32_t row_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const int32_t*)row_base;
@@ -149,8 +167,8 @@ __device__ __forceinline__ int lck_ctz64(uint64_t v) { return v ? __builtin_ctzl
 // G: rows between checkpoints; T: rows of a tile (a multiple of G).  A lane's tile starts on the checkpoint grid, as
 // low as leaves the row its path stands in inside the tile's last G rows: with T > G a path then covers at least
 // T - G rows of every tile it goes through upwards, where tiles on a grid of their own height are entered anywhere.
-template <int G, int T>
-__global__ void __launch_bounds__(64, 4) sa_long_ckpt_kernel(const SaPepParams P) {
+template <int G, int T, bool WIDE>
+__device__ __forceinline__ void sa_long_ckpt_body(const SaPepParams& P) {
     static_assert(G % 16 == 0 && 64 % G == 0 && T % G == 0 && T % 8 == 0 && T <= 64, "checkpoint rows 16, 32 or 64; tile rows a multiple, at most 64");
     extern __shared__ __align__(16) uint8_t smem[];
     int32_t* const prof = reinterpret_cast<int32_t*>(smem);
@@ -283,7 +301,7 @@ __global__ void __launch_bounds__(64, 4) sa_long_ckpt_kernel(const SaPepParams P
     {                                                                                                      \
         int oe_ = oend;                                                                                    \
         asm volatile("" : "+s"(oe_));                                                                      \
-        fill_row_score<decltype(full_tag)::value>(R, oe_, (DW), (LW), prof + (B) * SA_LCK_PS);             \
+        fill_row_score<decltype(full_tag)::value, WIDE>(R, oe_, (DW), (LW), prof + (B) * SA_LCK_PS);             \
     }                                                                                                      \
     if (decltype(cap_tag)::value && (RR) + 1 == lenq) {                                                    \
         capA = (int)(pick_packed<SA_LP>(R, colA) & 0xffffu) + base1;                                       \
@@ -456,7 +474,7 @@ __global__ void __launch_bounds__(64, 4) sa_long_ckpt_kernel(const SaPepParams P
     {                                                                                                      \
         int gr_ = gneed;                                                                                   \
         asm volatile("" : "+s"(gr_));                                                                      \
-        fill_row_pair<SA_LP / 4, SA_LCK_PS>(R, gr_, (DW) | SA_NB_UP_B, (LW), prof + (B) * SA_LCK_PS, e);  \
+        fill_row_pair<SA_LP / 4, SA_LCK_PS, 0, WIDE>(R, gr_, (DW) | SA_NB_UP_B, (LW), prof + (B) * SA_LCK_PS, e);  \
     }                                                                                                      \
     store_dirs(TT);
                     if (timed) tph[6] += (unsigned)((tmax + 4) & ~3);
@@ -606,8 +624,20 @@ __global__ void __launch_bounds__(64, 4) sa_long_ckpt_kernel(const SaPepParams P
 #undef SA_PHASE
 }
 
-extern "C" void sa_launch_long_ckpt(int ck_rows, const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream) {
-    if (ck_rows == 32)
+template <int G, int T>
+__global__ void __launch_bounds__(64, 4) sa_long_ckpt_kernel(const SaPepParams P) {
+    sa_long_ckpt_body<G, T, false>(P);
+}
+// the same kernel with its maxima as unsigned 16-bit instructions: tables whose values leave the half-precision range
+template <int G, int T>
+__global__ void __launch_bounds__(64, 4) sa_long_ckpt_wide_kernel(const SaPepParams P) {
+    sa_long_ckpt_body<G, T, true>(P);
+}
+
+extern "C" void sa_launch_long_ckpt(int ck_rows, int wide, const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream) {
+    if (wide)
+        hipLaunchKernelGGL((sa_long_ckpt_wide_kernel<64, 64>), dim3(grid), dim3(64), lds_bytes, stream, *p);
+    else if (ck_rows == 32)
         hipLaunchKernelGGL((sa_long_ckpt_kernel<32, 64>), dim3(grid), dim3(64), lds_bytes, stream, *p);
     else
         hipLaunchKernelGGL((sa_long_ckpt_kernel<64, 64>), dim3(grid), dim3(64), lds_bytes, stream, *p);

@@ -39,8 +39,8 @@ __device__ __forceinline__ uint32_t sa_pk_shl4_u16(uint32_t a) {     // each hal
     return r;
 }
 
-template <int WAVES_PER_SIMD>
-__global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_pair_kernel(const SaPepParams P) {
+template <bool WIDE>
+__device__ __forceinline__ void sa_long_pair_body(const SaPepParams& P) {
     extern __shared__ __align__(16) uint8_t smem[];
     int32_t* const prof = reinterpret_cast<int32_t*>(smem);
     uint8_t* const pseq = smem + SA_LDS_PROF_BYTES + 64;      // the two shared first sequences, lslot bytes each
@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_pair_kernel(const 
         /* pair of scalar registers (more than there are) and comes back as two vector instructions per group            */ \
         int gr_ = gend;                                                                                                    \
         asm volatile("" : "+s"(gr_));                                                                                      \
-        fill_row_pair<SA_LP / 4, SA_LONG_PAIR_PROF_STRIDE>(R, gr_, (DW) | SA_NB_UP_B, (LW), prof + (B) * SA_LONG_PAIR_PROF_STRIDE, e);           \
+        fill_row_pair<SA_LP / 4, SA_LONG_PAIR_PROF_STRIDE, 0, WIDE>(R, gr_, (DW) | SA_NB_UP_B, (LW), prof + (B) * SA_LONG_PAIR_PROF_STRIDE, e);           \
     }                                                                                                                      \
     store_dirs(RR);                                                                                                        \
     if ((RR) + 1 == lenq) {                                                                                                \
@@ -394,6 +394,19 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_pair_kernel(const 
 #undef SA_PHASE
 }
 
-extern "C" void sa_launch_long_pair(const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream) {
-    hipLaunchKernelGGL((sa_long_pair_kernel<4>), dim3(grid), dim3(64), lds_bytes, stream, *p);
+template <int WAVES_PER_SIMD>
+__global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_pair_kernel(const SaPepParams P) {
+    sa_long_pair_body<false>(P);
+}
+// the same kernel with its maxima as unsigned 16-bit instructions: tables whose values leave the half-precision range
+template <int WAVES_PER_SIMD>
+__global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_long_pair_wide_kernel(const SaPepParams P) {
+    sa_long_pair_body<true>(P);
+}
+
+extern "C" void sa_launch_long_pair(int wide, const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream) {
+    if (wide)
+        hipLaunchKernelGGL((sa_long_pair_wide_kernel<4>), dim3(grid), dim3(64), lds_bytes, stream, *p);
+    else
+        hipLaunchKernelGGL((sa_long_pair_kernel<4>), dim3(grid), dim3(64), lds_bytes, stream, *p);
 }

@@ -49,25 +49,38 @@
     "v_or_b32 %[ba], 0x80008, %[la]\n\t"                            \
     "v_pk_maximum3_f16 %[mb], %[mb], %[bb], %[la]\n\t"              \
     "v_bfi_b32 %[t], %[fielda], %[ma], %[mb]\n\t"
+// The same with the three-way maximum as two unsigned 16-bit maxima: one instruction more per column, and the whole
+// 16-bit range instead of the patterns below 0x7c00 (tables with larger entries, see packed_cells_mode in sa_api.cpp).
+#define SA_NB_HEAD_WIDE                                             \
+    "v_pk_max_u16 %[ma], %[ma], %[ba]\n\t"                          \
+    "v_pk_max_u16 %[ma], %[ma], %[zl]\n\t"                          \
+    "v_and_b32 %[la], 0xfff0fff0, %[ma]\n\t"                        \
+    "v_or_b32 %[ba], 0x80008, %[la]\n\t"                            \
+    "v_pk_max_u16 %[mb], %[mb], %[bb]\n\t"                          \
+    "v_pk_max_u16 %[mb], %[mb], %[la]\n\t"                          \
+    "v_bfi_b32 %[t], %[fielda], %[ma], %[mb]\n\t"
 #define SA_NB_TAIL "v_and_or_b32 %[bb], %[mb], %[clean], %[two]"
 #define SA_NB_OPERANDS(ACC_CONSTRAINT, B, C, MA, MB, ACC)                                                    \
     : [ma] "+v"(MA), [mb] "+v"(MB), [ba] "+v"(B[C]), [bb] "+v"(B[(C) + 1]), [la] "=&v"(la_), [t] "=&v"(t_),    \
       [acc] ACC_CONSTRAINT(ACC)                                                                              \
     : [zl] "v"(zl), [fielda] "s"(0x000c000cu), [clean] "s"(0xfff0fff0u), [two] "v"(upb), [low] "s"(0x000f000fu)
-#define SA_CELL_NB(B, C, MA, MB, ACC)                                                           \
+#define SA_CELL_NB_FORM(HEAD, B, C, MA, MB, ACC)                                                \
     {                                                                                           \
         uint32_t la_, t_;                                                                       \
         if (((C) & 7) == 0) {                                                                   \
-            asm volatile(SA_NB_HEAD "v_pk_lshlrev_b16 %[acc], 12, %[t] op_sel_hi:[0,1]\n\t" SA_NB_TAIL SA_NB_OPERANDS("=&v", B, C, MA, MB, ACC)); \
+            asm volatile(HEAD "v_pk_lshlrev_b16 %[acc], 12, %[t] op_sel_hi:[0,1]\n\t" SA_NB_TAIL SA_NB_OPERANDS("=&v", B, C, MA, MB, ACC)); \
         } else if (((C) & 7) == 2) {                                                            \
-            asm volatile(SA_NB_HEAD "v_and_b32 %[t], %[low], %[t]\n\tv_lshl_or_b32 %[acc], %[t], 8, %[acc]\n\t" SA_NB_TAIL SA_NB_OPERANDS("+v", B, C, MA, MB, ACC)); \
+            asm volatile(HEAD "v_and_b32 %[t], %[low], %[t]\n\tv_lshl_or_b32 %[acc], %[t], 8, %[acc]\n\t" SA_NB_TAIL SA_NB_OPERANDS("+v", B, C, MA, MB, ACC)); \
         } else if (((C) & 7) == 4) {                                                            \
-            asm volatile(SA_NB_HEAD "v_and_b32 %[t], %[low], %[t]\n\tv_lshl_or_b32 %[acc], %[t], 4, %[acc]\n\t" SA_NB_TAIL SA_NB_OPERANDS("+v", B, C, MA, MB, ACC)); \
+            asm volatile(HEAD "v_and_b32 %[t], %[low], %[t]\n\tv_lshl_or_b32 %[acc], %[t], 4, %[acc]\n\t" SA_NB_TAIL SA_NB_OPERANDS("+v", B, C, MA, MB, ACC)); \
         } else {                                                                                \
-            asm volatile(SA_NB_HEAD "v_and_or_b32 %[acc], %[t], %[low], %[acc]\n\t" SA_NB_TAIL SA_NB_OPERANDS("+v", B, C, MA, MB, ACC)); \
+            asm volatile(HEAD "v_and_or_b32 %[acc], %[t], %[low], %[acc]\n\t" SA_NB_TAIL SA_NB_OPERANDS("+v", B, C, MA, MB, ACC)); \
         }                                                                                       \
         zl = MB;                                                                                \
     }
+#define SA_CELL_NB(B, C, MA, MB, ACC)                                                           \
+    if constexpr (WIDE) SA_CELL_NB_FORM(SA_NB_HEAD_WIDE, B, C, MA, MB, ACC)                     \
+    else SA_CELL_NB_FORM(SA_NB_HEAD, B, C, MA, MB, ACC)
 
 // Four columns.  Rows end early: after gend = ceil(longer first sequence / 4) groups, a run-time value, when the
 // template argument END2 is 0; otherwise after END2 = ceil(longer first sequence / 2) column pairs, a constant: no
@@ -123,7 +136,8 @@ typedef int sa_i32x2 __attribute__((ext_vector_type(2)));
 // lane's profile row, PS dwords long, laid out as described above.
 // e[w] receives the tags of columns 8w .. 8w+7 of both pairs: column 8w+i at bits 2(7-i) of each 16-bit
 // half, also when the row ends after four columns of the word.
-template <int NG, int PS, int END2 = 0>
+// WIDE: the maxima as unsigned 16-bit instructions (SA_NB_HEAD_WIDE).
+template <int NG, int PS, int END2 = 0, bool WIDE = false>
 __device__ __forceinline__ void fill_row_pair(uint32_t (&B)[4 * NG], const int gend,
                                               const uint32_t diag0, const uint32_t left0,
                                               const int32_t* __restrict__ row_base, uint32_t (&e)[(NG + 1) / 2]) {

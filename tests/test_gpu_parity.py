@@ -172,11 +172,14 @@ def test_longest_supported_sequences():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("gap,top,rows_between_rebases", [(-5, 15, 8), (-6, 15, 8), (-6, 16, 4), (-7, 15, None)])
-def test_packed_long_kernels_at_the_edge_of_their_table_range(gap, top, rows_between_rebases):
-    """Tagged 16-bit cells hold 16 (D - base) below 0x7c00; a long strip is 64 columns wide and the bases move every 16, 8
-    or 4 rows, the more often the larger the table's entries: shifted scores up to 24, 27, 28.  Runs of one letter whose
-    self-score is the table's largest entry make D grow by that much per step; beyond 28 the 32-bit kernel runs."""
+@pytest.mark.parametrize("gap,top,form", [(-5, 15, ""), (-6, 15, ""), (-6, 16, ""), (-7, 15, "wide_"), (-12, 15, "wide_"), (-17, 16, "wide_"),
+                                          (-20, 16, "wide_"), (-22, 15, "wide_"), (-22, 16, None)])
+def test_packed_long_kernels_at_the_edge_of_their_table_range(gap, top, form):
+    """Tagged 16-bit cells hold 16 (D - base); a long strip is 64 columns wide and the bases move every 16, 8 or 4 rows,
+    the more often the larger the table's entries.  With the maximum as one half-precision instruction the patterns stay
+    below 0x7c00: shifted scores up to 24, 27, 28.  Beyond that the kernels' wide forms run (unsigned 16-bit maxima, the
+    whole 16-bit range): up to 50, 56, 59; then the 32-bit kernel.  Runs of one letter whose self-score is the table's
+    largest entry make D grow by that much per step."""
     rng = random.Random(31 + top - gap)
     matrix = [rng.randint(-3, 6) for _ in range(400)]
     for a in range(20):
@@ -195,10 +198,10 @@ def test_packed_long_kernels_at_the_edge_of_their_table_range(gap, top, rows_bet
     for rows in (64, 0):
         al.set_long_checkpoint_rows(rows)
         rec = al.align(sa.TRIANGULAR)
-        if rows_between_rebases is None:
+        if form is None:
             assert al.last_kernel() == "sa_long_kernel<0, 2>"          # the table does not fit packed cells
         else:
-            assert al.last_kernel() == ("sa_long_ckpt_kernel<64, 64>" if rows else "sa_long_pair_kernel<4>")
+            assert al.last_kernel() == ("sa_long_ckpt_%skernel<64, 64>" % form if rows else "sa_long_pair_%skernel<4>" % form)
         if ref is None:
             ref = rec
             _check_pairs(al, rec[: n - 1], [(0, j) for j in range(1, n)], gap=gap, matrix=matrix)
@@ -574,16 +577,18 @@ def test_long_paired_and_unpaired_kernels_give_identical_records(n, lo, hi, seed
 
 @pytest.mark.gpu
 def test_long_paired_kernel_at_the_edge_of_its_range():
-    """S - 2*gap up to 28 is the most the long paired kernels take (registers hold at most 16 * 81 * 24 + 15 with the
-    bases moved every 16 rows, 16 * 69 * 28 + 15 with every 4: below the first half-precision pattern that is not a
-    finite number); one more and the library must use 32-bit cells by itself.  Sequences of one letter reach the
+    """S - 2*gap up to 28 is the most the long paired kernels take in their first form (registers hold at most
+    16 * 81 * 24 + 15 with the bases moved every 16 rows, 16 * 69 * 28 + 15 with every 4: below the first half-precision
+    pattern that is not a finite number), up to 59 in their wide form (16 * 69 * 59 + 15 < 65536); one more and the
+    library must use 32-bit cells by itself.  Sequences of one letter reach the
     largest D.  At the lower edge (1 for a mismatch) the candidates tie all the time; with 0 the 32-bit cells take
     over."""
     rng = random.Random(9)
     seqs = ["".join(rng.choice("AAAR") for _ in range(rng.choice([400, 333, 256, 129]))) for _ in range(70)]
     n = len(seqs)
     # (match score, lowest mismatch score): S' = score + 8
-    for top, worst, expect_pairs in ((16, 13, True), (17, 14, True), (20, 17, True), (21, 18, False), (16, -7, True), (16, -8, False)):
+    for top, worst, expect_pairs in ((16, 13, True), (17, 14, True), (20, 17, True), (21, 18, True), (51, 40, True), (52, 40, False),
+                                     (16, -7, True), (16, -8, False)):
         matrix = [top if a == b else worst + rng.randint(0, 3) for a in range(20) for b in range(20)]
         matrix[1] = matrix[20] = worst          # A/R, the two letters in use
         al = sa.Aligner(gap=-4, matrix=matrix, max_seq_len=400)

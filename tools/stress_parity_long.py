@@ -1,6 +1,7 @@
 """Randomised parity sweep of the long-sequence kernels (run on a GPU box; not part of the test suite: it takes minutes).
 python tools/stress_parity_long.py [first_seed] [count]
-Each case draws a table that keeps the packed kernel in range (shifted scores 1..28: bases moved every 16, 8 or 4 rows), a gap penalty, an alphabet of 2..20
+Each case draws a table that keeps the packed kernels in range (shifted scores 1..59: half-precision or unsigned
+maxima, bases moved every 16, 8 or 4 rows), a gap penalty, an alphabet of 2..20
 letters (small ones give long runs of gaps and many ties), 70-260 sequences and a wide length range (65 .. 1500: pairs
 whose lengths differ by a factor of ten have runs of LEFT or UP moves hundreds of columns long, which cross several
 64-column strips in one row); every record of the all-vs-all schedule is compared between the packed and the 32-bit
@@ -20,7 +21,8 @@ bad = 0
 for seed in range(first, first + count):
     rng = random.Random(9000 + seed)
     gap = -rng.randint(1, 8)
-    hi_s = rng.randint(2, 28 + 2 * gap if 28 + 2 * gap >= 2 else 2)          # S' = S - 2 gap <= 28
+    top = rng.choice([24, 28, 50, 59])                                        # S' = S - 2 gap <= top: the kernels' two forms
+    hi_s = rng.randint(2, top + 2 * gap if top + 2 * gap >= 2 else 2)
     lo_s = max(1 + 2 * gap, hi_s - rng.randint(1, 20))                       # S' >= 1
     matrix = [rng.randint(lo_s, hi_s) for _ in range(400)]
     letters = ALPHABET[: rng.choice([2, 3, 4, 8, 20, 20])]
