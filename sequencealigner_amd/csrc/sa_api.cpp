@@ -24,7 +24,7 @@ extern "C" void sa_launch_peptide(int mode, int waves_per_simd, const SaPepParam
 extern "C" void sa_launch_pack_slots(const uint8_t* codes, const uint64_t* offs, const uint32_t* lens, uint64_t nseq,
                                      uint64_t nslots, uint32_t lslot, uint8_t* slots, uint16_t* len16, hipStream_t stream);
 extern "C" void sa_launch_digest(const void* records, uint64_t bytes, unsigned long long* acc, hipStream_t stream);
-extern "C" void sa_launch_peptide_pair(int ng, const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream);
+extern "C" void sa_launch_peptide_pair(int ng, int wide, const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream);
 extern "C" size_t sa_format_scan_bytes(uint64_t n);
 extern "C" hipError_t sa_launch_format(const SaFormatParams* F, void* scan_tmp, size_t scan_bytes, hipStream_t stream);
 extern "C" void sa_launch_long_pair(int wide, const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream);
@@ -197,7 +197,7 @@ void table_range(const int32_t* S, int32_t gap, int64_t& low, int64_t& top) {
 }
 // Packed 16-bit cells hold 16 (D - base) + two tag fields.  With the three-way maximum as one v_pk_maximum3_f16 the
 // patterns must stay below 0x7c00: D - base <= 1983 ("narrow").  With two v_pk_max_u16 per maximum (one instruction
-// more per column) the whole 16-bit range is usable: D - base <= 4095 ("wide"; long sequences only).
+// more per column) the whole 16-bit range is usable: D - base <= 4095 ("wide").
 // Peptides: base 0, D grows by at most max S' per row and column, so longest sequence x max S' must fit.  Long
 // sequences: a strip is 64 columns wide and the lanes' bases move up to the row above every R rows, so
 // (64 + R + 1) x max S' must fit; R = 16 where the table allows it, else 8 or 4 -- a move of the bases is 64
@@ -215,7 +215,7 @@ int packed_cells_mode(const sa_ctx* c, bool lng) {
     if (c->sprime_min < 1) return kCellsNone;
     if (lng) return long_rebase_rows(c, 1983) ? kCellsNarrow : long_rebase_rows(c, 4095) ? kCellsWide : kCellsNone;
     const int64_t span = std::max<int64_t>(1, std::min<int64_t>(c->max_seq, SA_LP));
-    return span * c->sprime_max <= 1983 ? kCellsNarrow : kCellsNone;
+    return span * c->sprime_max <= 1983 ? kCellsNarrow : span * c->sprime_max <= 4095 ? kCellsWide : kCellsNone;
 }
 bool packed_cells_fit(const sa_ctx* c, bool lng) { return packed_cells_mode(c, lng) != kCellsNone; }
 
@@ -594,7 +594,7 @@ int launch_work(sa_ctx* c, Work& w, bool timed) {
     if (timed) SA_HIP_TRY(hipEventRecord(w.t0, c->compute));
     P.lslot = c->lslot;
     P.bcol = (int32_t*)c->d_bcol.p;
-    const bool wide = is_long(c) && packed_cells_mode(c, true) == kCellsWide;
+    const bool wide = packed_cells_mode(c, is_long(c)) == kCellsWide;
     P.rebase_mask = std::max<uint32_t>(long_rebase_rows(c, wide ? 4095 : 1983), 4) - 1;
     const bool tri = w.schedule == SA_SCHEDULE_TRIANGULAR;
     if (w.coop) {
@@ -628,8 +628,9 @@ int launch_work(sa_ctx* c, Work& w, bool timed) {
         sa_launch_long(tri ? 0 : 1, &P, grid, SA_LDS_PROF_BYTES + 64 + c->lslot, c->compute);
         c->last_kernel = tri ? "sa_long_kernel<0, 2>" : "sa_long_kernel<1, 2>";
     } else if (tri && w.paired) {
-        sa_launch_peptide_pair(pair_groups(c), &P, grid, SA_PAIR_LDS_BYTES(pair_groups(c)), c->compute);
-        c->last_kernel = pair_groups(c) <= 13 ? "sa_peptide_pair_kernel<13, 4>" : "sa_peptide_pair_kernel<16, 4>";
+        sa_launch_peptide_pair(pair_groups(c), wide ? 1 : 0, &P, grid, SA_PAIR_LDS_BYTES(pair_groups(c)), c->compute);
+        c->last_kernel = wide ? (pair_groups(c) <= 13 ? "sa_peptide_pair_wide_kernel<13, 4>" : "sa_peptide_pair_wide_kernel<16, 4>")
+                              : (pair_groups(c) <= 13 ? "sa_peptide_pair_kernel<13, 4>" : "sa_peptide_pair_kernel<16, 4>");
     } else {
         const int waves = (c->wg_per_cu == 0 || c->wg_per_cu > 8) ? 3 : 2;
         sa_launch_peptide(tri ? 0 : 1, waves, &P, grid, SA_LDS_FIXED_BYTES, c->compute);

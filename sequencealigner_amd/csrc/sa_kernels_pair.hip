@@ -20,8 +20,9 @@
 #include "sa_pair_common.h"
 #include "sa_traceback.h"
 
-template <int NG, int WAVES_PER_SIMD>
-__global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(const SaPepParams P) {
+// WIDE: the three-way maxima as two unsigned 16-bit maxima each (sa_pair_common.h): longest sequence * max S' <= 4095.
+template <int NG, bool WIDE>
+__device__ __forceinline__ void sa_peptide_pair_body(const SaPepParams& P) {
     constexpr int NC = 4 * NG;
     constexpr int NACC = (NG + 1) / 2;
     extern __shared__ __align__(16) uint8_t smem[];
@@ -236,7 +237,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
                     // residues; those rows are never read): with the row under a per-lane condition the compiler
                     // keeps a second copy of the register row for the lanes that skip it.  A lane takes its
                     // scores when its last row is done.
-                    fill_row_pair<NG, PS, END2>(R, (END2 + 1) / 2, SA_NB_UP_B, 0u, prof + o0, e);
+                    fill_row_pair<NG, PS, END2, WIDE>(R, (END2 + 1) / 2, SA_NB_UP_B, 0u, prof + o0, e);
                     store_dirs(r, GC);
                     if (r + 1 == lenq) {
                         dfin1 = pick_packed<NC>(R, lenp1 - 1);
@@ -372,11 +373,27 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(con
 #undef SA_PHASE
 }
 
+template <int NG, int WAVES_PER_SIMD>
+__global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_kernel(const SaPepParams P) {
+    sa_peptide_pair_body<NG, false>(P);
+}
+// the same kernel for tables whose values leave the range of the half-precision patterns
+template <int NG, int WAVES_PER_SIMD>
+__global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_wide_kernel(const SaPepParams P) {
+    sa_peptide_pair_body<NG, true>(P);
+}
+
 // ng: 4-column groups the register row holds (13: sequences up to 52 residues, 16: up to 64).  Both fit 128
 // registers, four waves per SIMD; the shorter row leaves room in the LDS for one more workgroup per CU.
-extern "C" void sa_launch_peptide_pair(int ng, const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream) {
-    if (ng <= 13)
+extern "C" void sa_launch_peptide_pair(int ng, int wide, const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream) {
+    if (wide) {
+        if (ng <= 13)
+            hipLaunchKernelGGL((sa_peptide_pair_wide_kernel<13, 4>), dim3(grid), dim3(64), lds_bytes, stream, *p);
+        else
+            hipLaunchKernelGGL((sa_peptide_pair_wide_kernel<16, 4>), dim3(grid), dim3(64), lds_bytes, stream, *p);
+    } else if (ng <= 13) {
         hipLaunchKernelGGL((sa_peptide_pair_kernel<13, 4>), dim3(grid), dim3(64), lds_bytes, stream, *p);
-    else
+    } else {
         hipLaunchKernelGGL((sa_peptide_pair_kernel<16, 4>), dim3(grid), dim3(64), lds_bytes, stream, *p);
+    }
 }

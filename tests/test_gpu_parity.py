@@ -492,19 +492,25 @@ def test_unpaired_kernel_csv_equals_golden_hash(tmp_path):
 @pytest.mark.gpu
 def test_paired_kernel_at_the_edge_of_its_16_bit_range():
     """S - 2*gap = 30 everywhere a residue matches and 28..30 elsewhere, 64 residues: the largest values the
-    packed cells may hold (16 * 64 * 30 + 15 is below the first half-precision pattern that is not a finite
-    number).  One step beyond, the library must take the 32-bit kernel by itself."""
+    packed cells may hold in the kernel's first form (16 * 64 * 30 + 15 is below the first half-precision pattern that
+    is not a finite number).  One step beyond, its wide form runs (unsigned 16-bit maxima: up to 16 * 64 * 63 + 15), and
+    beyond that the library must take the 32-bit kernel by itself."""
     rng = random.Random(5)
     seqs = ["".join(rng.choice(ALPHABET[:4]) for _ in range(rng.choice([64, 64, 63, 50]))) for _ in range(140)]
     n = len(seqs)
-    for top, expect_pairs in ((22, True), (23, False)):
+    for top, kernel in ((22, "sa_peptide_pair_kernel<16, 4>"), (23, "sa_peptide_pair_wide_kernel<16, 4>"),
+                        (55, "sa_peptide_pair_wide_kernel<16, 4>"), (56, "sa_peptide_kernel<0, 3>")):
         matrix = [top if a == b else top - rng.randint(0, 2) for a in range(20) for b in range(20)]
         al = sa.Aligner(gap=-4, matrix=matrix, max_seq_len=64)
         al.upload(seqs)
         items = al.work_items(sa.TRIANGULAR, 0, n - 1).tolist()
-        assert any(it[5] != 0xFFFFFFFF for it in items) == expect_pairs
+        assert any(it[5] != 0xFFFFFFFF for it in items) == ("pair" in kernel)
         rec = al.align(sa.TRIANGULAR)
+        assert al.last_kernel() == kernel
         _check_pairs(al, rec, _tri_pairs(n, 0, n - 1), gap=-4, matrix=matrix)
+        if "pair" in kernel:
+            al.set_pairing(False)
+            assert np.array_equal(al.align(sa.TRIANGULAR), rec)
 
 
 @pytest.mark.gpu

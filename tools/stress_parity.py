@@ -1,6 +1,6 @@
 """Randomised parity sweep, paired peptide kernel against the CPU checker (run on a GPU box; not part of the test suite:
 it takes minutes).  python tools/stress_parity.py [first_seed] [count]
-Each case draws a table that keeps the packed kernel in range (shifted scores 1..24), a gap penalty, an alphabet of 2..20
+Each case draws a table that keeps the packed kernel in range (shifted scores 1..63: half-precision or unsigned maxima), a gap penalty, an alphabet of 2..20
 letters (small ones give long runs of gaps and many ties), a number of sequences (few: wide buckets, partners of
 different lengths; many: exact-length buckets) and a length range; every record of the all-vs-all schedule is compared
 between the packed and the 32-bit kernel, and a sample of rows with the checker."""
@@ -19,7 +19,8 @@ bad = 0
 for seed in range(first, first + count):
     rng = random.Random(5000 + seed)
     gap = -rng.randint(1, 8)
-    hi_s = rng.randint(2, 24 + 2 * gap if 24 + 2 * gap >= 2 else 2)          # S' = S - 2 gap <= 24
+    top = rng.choice([24, 30, 63])                                            # S' = S - 2 gap <= top: the kernel's two forms
+    hi_s = rng.randint(2, top + 2 * gap if top + 2 * gap >= 2 else 2)
     lo_s = max(1 + 2 * gap, hi_s - rng.randint(1, 20))                       # S' >= 1
     matrix = [rng.randint(lo_s, hi_s) for _ in range(400)]
     letters = ALPHABET[: rng.choice([2, 3, 4, 8, 20, 20])]
