@@ -260,9 +260,11 @@ def resident_measurement(sa, synth, name, device, launches=2, pairing=True, chec
     al.run_resident()
     ms = [al.run_resident() for _ in range(launches)]
     kernel = al.last_kernel()
+    grid = al.last_grid()
     al.close()
     k_ms = sum(ms) / len(ms)
-    out = {"workload": desc, "kernel": kernel, "pairs": pairs, "cells": cells, "kernel_ms": round(k_ms, 3),
+    out = {"workload": desc, "kernel": kernel, "workgroups": grid[0], "workgroups_wanted": grid[1], "pairs": pairs, "cells": cells,
+           "kernel_ms": round(k_ms, 3),
            "gcups": round(cells / k_ms / 1e6, 1), "pairs_per_s": round(pairs / k_ms * 1e3, 1),
            "roofline_frac": round(cells * OPS_PER_CELL / (k_ms * 1e-3) / 1e12 / PEAK_TIOPS, 4)}
     if "pair_kernel" in kernel or "ckpt" in kernel:

@@ -218,6 +218,12 @@ int sa_set_cooperative_waves(sa_ctx* ctx, int waves);
 /* name of the fill + traceback kernel the context's most recent launch ran ("" before the first): the library picks
  * between packed 16-bit and 32-bit cells, peptide and strip kernels from the table, the lengths and the row range */
 const char* sa_last_kernel(const sa_ctx* ctx);
+/* workgroups of that launch, and how many it would have had with memory to spare: the long-sequence kernels keep a
+ * scratch area per workgroup (up to 31 MiB for 1000-residue proteins), sized at the first launch after an upload from
+ * what is free on the device then (three quarters of it at most, never the last 16 GiB); a context that shares its
+ * card with others gets fewer workgroups, i.e. fewer waves per SIMD, and this call says so.  No counterpart in the
+ * reference. */
+int sa_last_grid(const sa_ctx* ctx, uint32_t* workgroups, uint32_t* wanted);
 
 /* diagnostic: with enable != 0 the next launches accumulate shader cycles per kernel
  * phase (0 queue fetch, 1 profile build, 2 operand set-up, 3 fill, 4 traceback,

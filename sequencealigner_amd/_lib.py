@@ -138,6 +138,7 @@ SIGNATURES = {
     "sa_set_tuning": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     "sa_set_bucket_width": (C.c_int, [C.c_void_p, C.c_uint32]),
     "sa_last_kernel": (C.c_char_p, [C.c_void_p]),
+    "sa_last_grid": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "sa_set_pairing": (C.c_int, [C.c_void_p, C.c_int]),
     "sa_set_cooperative": (C.c_int, [C.c_void_p, C.c_int]),
     "sa_set_cooperative_waves": (C.c_int, [C.c_void_p, C.c_int]),
@@ -472,6 +473,12 @@ class Aligner:
     def last_kernel(self):
         """Name of the fill + traceback kernel the most recent launch ran."""
         return self._lib.sa_last_kernel(self._ctx).decode()
+
+    def last_grid(self):
+        """(workgroups of the most recent launch, workgroups it would have had with memory to spare)."""
+        a, b = C.c_uint32(), C.c_uint32()
+        _check(self._lib.sa_last_grid(self._ctx, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def phase_cycles(self, enable=True):
         """Shader-cycle totals per kernel phase of the previous timed launch; (re)arms the timers."""

@@ -179,6 +179,7 @@ struct sa_ctx {
     Work resident;
     bool resident_ready = false;
     const char* last_kernel = "";      // name of the fill + traceback kernel of the most recent launch
+    uint32_t last_grid = 0, last_grid_wanted = 0;    // its workgroups, and how many it would have had with memory to spare
 };
 
 namespace {
@@ -558,6 +559,14 @@ int launch_work(sa_ctx* c, Work& w, bool timed) {
         c->spill_budget = std::max<uint64_t>(std::min<uint64_t>(room, (uint64_t)free_b / 4 * 3), 1ull << 30);
     }
     const uint32_t grid = grid_for(c);
+    c->last_grid = grid;
+    {
+        // the same count without the limit that the scratch areas' memory puts on long-sequence launches
+        const uint64_t budget = c->spill_budget;
+        c->spill_budget = ~0ull;
+        c->last_grid_wanted = grid_for(c);
+        c->spill_budget = budget;
+    }
     int rc = w.coop ? SA_OK : ensure_spill(c, grid);
     if (rc) return rc;
     SA_HIP_TRY(hipMemsetAsync(w.counter.p, 0, 256, c->compute));
@@ -603,6 +612,7 @@ int launch_work(sa_ctx* c, Work& w, bool timed) {
         uint64_t wg_per_cu = 16 / waves;
         if (waves > 1) wg_per_cu = std::max<uint64_t>(1, std::min<uint64_t>(wg_per_cu, (160u * 1024u) / (sa_coop_wg_lds_bytes(c->lslot, waves) + 4096u)));
         const uint32_t cgrid = (uint32_t)std::min<uint64_t>(w.nitems, (uint64_t)c->ncu * wg_per_cu);
+        c->last_grid = c->last_grid_wanted = cgrid;
         const uint32_t kib = coop_kib_per_wg(c);
         if ((rc = c->d_coop.reserve((size_t)cgrid * kib * 1024))) return rc;
         P.spill = (uint32_t*)c->d_coop.p;
@@ -1449,6 +1459,13 @@ int sa_set_pairing(sa_ctx* c, int enable) {
 }
 
 const char* sa_last_kernel(const sa_ctx* c) { return c ? c->last_kernel : ""; }
+
+int sa_last_grid(const sa_ctx* c, uint32_t* workgroups, uint32_t* wanted) {
+    if (!c || !workgroups || !wanted) return SA_ERR_ARG;
+    *workgroups = c->last_grid;
+    *wanted = c->last_grid_wanted;
+    return SA_OK;
+}
 
 int sa_debug_work_items(sa_ctx* c, int schedule, uint64_t r0, uint64_t r1, uint32_t* items8, uint64_t cap,
                         uint64_t* count) {

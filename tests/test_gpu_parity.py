@@ -387,6 +387,9 @@ def test_full_size_protein_set_sampled_against_oracle():
     al.prepare_resident(sa.TRIANGULAR, 0, rows)
     al.run_resident()
     assert al.last_kernel() == "sa_long_ckpt_kernel<64, 64>"
+    # alone on the card the launch gets every workgroup it wants: sixteen per CU (four waves per SIMD)
+    grid, wanted = al.last_grid()
+    assert grid == wanted and grid % 16 == 0 and grid >= 16 * 64
     rng = random.Random(77)
     picks = [(0, 1), (0, n - 1), (n - 2, n - 1), (n - 3, n - 2), (1, 2)]
     while len(picks) < 340:
