@@ -65,6 +65,7 @@ WORKLOADS = {
     "peptides4k": (4000, 6, 50, 1, "synthetic 4k peptides len 6-50 seed 1, all-vs-all"),
     "proteins10k": (10000, 300, 1000, 2, "synthetic 10k proteins len 300-1000 seed 2, all-vs-all (BASELINE.json configs[4])"),
     "proteins2k": (2000, 300, 1000, 2, "first 2000 of the synthetic proteins len 300-1000 seed 2, all-vs-all"),
+    "domains16k": (16000, 65, 128, 3, "synthetic 16k sequences len 65-128 seed 3, all-vs-all (between the two regimes)"),
     # the reference's enlarged data set (BASELINE.json configs[3]): no generator, read from the golden avpdb.csv
     "mega": (4001280, 2, 46, None, "mega data set: avpdb.csv forwards + backwards x 1920, 4 001 279 adjacent pairs"),
     # few long pairs: the workgroup-per-pair kernel's case
@@ -598,6 +599,8 @@ def main():
                     extra["proteins2k"] = resident_measurement(sa, synth, "proteins2k", local_rank)
                     extra["proteins2k_direction_rows_kernel"] = resident_measurement(sa, synth, "proteins2k", local_rank, checkpoint_rows=0)
                     extra["proteins10k"] = resident_measurement(sa, synth, "proteins10k", local_rank, launches=1)
+                    # between the two regimes: sequences a little longer than the peptide kernel's 64 columns
+                    extra["domains16k"] = resident_measurement(sa, synth, "domains16k", local_rank, launches=1)
                 out["extra"] = extra
                 if args.cpu_sample > 0:
                     out["cpu_baseline"] = cpu_baseline(sa, synth, seqs, labels, min(args.cpu_sample, n) if hi <= 64 else min(300, n),
