@@ -489,8 +489,8 @@ uint32_t coop_kib_per_wg(const sa_ctx* c) {
 
 // Which packed long-sequence kernel, left to the library: the checkpointing kernel fills again a 64-row tile per strip
 // and path, which for short sequences is most of the matrix; keeping two direction bits per cell is then cheaper.
-// All-vs-all sets, TCUPS checkpointing / direction rows: lengths 65-128 4.5 / 5.4, 100-300 6.7 / 7.2, 200-500 9.4 / 9.7,
-// 600-1400 16.2 / 10.6, 1500-3000 13.8 / 5.0 (tools/midlen_time.py).
+// All-vs-all sets, TCUPS checkpointing / direction rows: lengths 65-128 4.5 / 5.7, 100-300 6.8 / 7.6, 200-500 9.4 / 9.9,
+// 600-1400 16.1 / 10.5, 1500-3000 13.7 / 4.8 (tools/midlen_time.py).
 uint32_t long_auto_checkpoint_rows(uint32_t longest) { return longest >= 512 ? 64u : 0u; }
 
 // rows of the checkpointing kernel's border columns and checkpoints: the longest uploaded sequence, rounded up to 64

@@ -28,6 +28,7 @@
 #include <type_traits>
 
 #include "sa_pair_common.h"
+#include "sa_long_walk.h"
 
 #define SA_LCK_PS SA_PAIR_PROF_STRIDE(16)   /* 66 dwords; the LDS is sized for 68 (SA_LDS_PROF_BYTES) */
 
@@ -105,8 +106,6 @@ __device__ __forceinline__ uint32_t lck_pk_shl4(uint32_t a) {     // each half s
     if constexpr (WIDE) SA_SC_GROUP_FORM(SA_SC_ADDS_MAXS_WIDE, G, SC)                               \
     else SA_SC_GROUP_FORM(SA_SC_ADDS_MAXS, G, SC)
 typedef int sa_i32x4v __attribute__((ext_vector_type(4)));
-typedef uint32_t sa_u32x4v __attribute__((ext_vector_type(4)));
-typedef uint32_t sa_u32x2v __attribute__((ext_vector_type(2)));
 #ifdef SA_LCK_EXP_NO_LDS     /* experiment: no table reads at all (wrong results, same arithmetic) */
 #define SA_SC_REQ8(LO, HI, O) asm volatile("" : "=v"(LO), "=v"(HI))
 #define SA_SC_PENDING "0"
@@ -160,8 +159,6 @@ __device__ __forceinline__ void fill_row_score(uint32_t (&B)[SA_LP], const int o
     SA_SC_OCTET(6, pa_lo, pa_hi, pb_lo, pb_hi) SA_SC_OCTET(7, pb_lo, pb_hi, pa_lo, pa_hi)
 }
 
-// position of the lowest set bit of a 64-bit value, 64 for 0
-__device__ __forceinline__ int lck_ctz64(uint64_t v) { return v ? __builtin_ctzll(v) : 64; }
 
 #ifndef SA_LCK_ROW_BENCH     /* tools/row_bench.hip takes the row functions alone */
 // G: rows between checkpoints; T: rows of a tile (a multiple of G).  A lane's tile starts on the checkpoint grid, as
@@ -381,18 +378,6 @@ __device__ __forceinline__ void sa_long_ckpt_body(const SaPepParams& P) {
             // that starts a group of eight is done.  (One 2-byte store per row and lane -- 64 partial lines per wave and
             // row -- cost a third of the launch.)  Rows of the first group beyond the sequence's end stay zero.
             uint32_t wacc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-#define SA_LCK_PUSH(H, REC, ROW, CODE)                                                                                     \
-    {                                                                                                                      \
-        wacc[H][3] = __builtin_amdgcn_alignbit(wacc[H][3], wacc[H][2], 16);                                                \
-        wacc[H][2] = __builtin_amdgcn_alignbit(wacc[H][2], wacc[H][1], 16);                                                \
-        wacc[H][1] = __builtin_amdgcn_alignbit(wacc[H][1], wacc[H][0], 16);                                                \
-        wacc[H][0] = (wacc[H][0] << 16) | (uint32_t)(CODE);                                                                \
-        if (((ROW) & 7) == 0) {                                                                                            \
-            *reinterpret_cast<uint4*>((REC) + SA_LONG_HEADER_BYTES + 2 * (size_t)(ROW)) =                                  \
-                make_uint4(wacc[H][0], wacc[H][1], wacc[H][2], wacc[H][3]);                                                \
-            wacc[H][0] = wacc[H][1] = wacc[H][2] = wacc[H][3] = 0;                                                         \
-        }                                                                                                                  \
-    }
             uint8_t* const rec0 = out_row1 + (size_t)(fiq - p1 - 1) * P.stride;
             uint8_t* const rec1 = out_row2 + (size_t)(fiq - p2 - 1) * P.stride;
 #ifdef SA_LCK_EXP_NO_PASS2
@@ -517,70 +502,6 @@ __device__ __forceinline__ void sa_long_ckpt_body(const SaPepParams& P) {
                     const uint8_t* const resp = bslot + r0;
                     sa_u32x4v a0x, a1x, a2x, a3x, a4x, a5x, a6x, a7x, b0x, b1x, b2x, b3x, b4x, b5x, b6x, b7x;
                     sa_u32x2v rx;
-#define SA_LCK_FETCH(CH)                                                                                                 \
-    {                                                                                                                    \
-        /* a lane asks for the rows of a half only if its path of that half stands in or below this chunk: the other   \
-           lanes' rows were not stored either */                                                                         \
-        const unsigned long long needA_ = __ballot(tc0 >= 8 * (CH)), needB_ = __ballot(tc1 >= 8 * (CH));                 \
-        unsigned long long all_;                                                                                         \
-        asm volatile("s_mov_b64 %[all], exec\n\t"                                                                        \
-                 "s_and_b64 exec, %[all], %[na]\n\t"                                                                     \
-                 "global_load_dwordx4 %0, %[vo], %[a0]\n\tglobal_load_dwordx4 %1, %[vo], %[a0] offset:1024\n\t"          \
-                 "global_load_dwordx4 %2, %[vo], %[a0] offset:2048\n\tglobal_load_dwordx4 %3, %[vo], %[a0] offset:3072\n\t" \
-                 "global_load_dwordx4 %4, %[vo], %[a1]\n\tglobal_load_dwordx4 %5, %[vo], %[a1] offset:1024\n\t"          \
-                 "global_load_dwordx4 %6, %[vo], %[a1] offset:2048\n\tglobal_load_dwordx4 %7, %[vo], %[a1] offset:3072\n\t" \
-                 "s_and_b64 exec, %[all], %[nb]\n\t"                                                                     \
-                 "global_load_dwordx4 %8, %[vo], %[b0]\n\tglobal_load_dwordx4 %9, %[vo], %[b0] offset:1024\n\t"          \
-                 "global_load_dwordx4 %10, %[vo], %[b0] offset:2048\n\tglobal_load_dwordx4 %11, %[vo], %[b0] offset:3072\n\t" \
-                 "global_load_dwordx4 %12, %[vo], %[b1]\n\tglobal_load_dwordx4 %13, %[vo], %[b1] offset:1024\n\t"        \
-                 "global_load_dwordx4 %14, %[vo], %[b1] offset:2048\n\tglobal_load_dwordx4 %15, %[vo], %[b1] offset:3072\n\t" \
-                 "s_mov_b64 exec, %[all]\n\t"                                                                            \
-                 "global_load_dwordx2 %16, %[rp], off\n\t"                                                               \
-                 "s_waitcnt vmcnt(0)"                                                                                    \
-                 : "=&v"(a0x), "=&v"(a1x), "=&v"(a2x), "=&v"(a3x), "=&v"(a4x), "=&v"(a5x), "=&v"(a6x), "=&v"(a7x),        \
-                   "=&v"(b0x), "=&v"(b1x), "=&v"(b2x), "=&v"(b3x), "=&v"(b4x), "=&v"(b5x), "=&v"(b6x), "=&v"(b7x), "=&v"(rx), \
-                   [all] "=&s"(all_)                                                                                     \
-                 : [vo] "v"(voff), [a0] "s"(tile_a + (size_t)(CH) * 8192), [a1] "s"(tile_a + (size_t)(CH) * 8192 + 4096), \
-                   [b0] "s"(tile_b + (size_t)(CH) * 8192), [b1] "s"(tile_b + (size_t)(CH) * 8192 + 4096),                 \
-                   [rp] "v"(resp + 8 * (CH)), [na] "s"(needA_), [nb] "s"(needB_)                                          \
-                 : "memory", "scc");                                                                                     \
-    }
-#define SA_LCK_STEP(H, TC, D, REC)                                                                                         \
-    if ((TC) == t) {                                                                                                       \
-        const int jl = wj[H] - cbase;                         /* columns of this strip still to go: 1 .. 64 */             \
-        const uint64_t v0 = ((uint64_t)(D).x << 32) | (D).y;                                                               \
-        const uint64_t v1 = ((uint64_t)(D).z << 32) | (D).w;                                                               \
-        const bool upper = jl > 32;                                                                                        \
-        const int jj = upper ? jl - 32 : jl;                                                                               \
-        const uint64_t x = (upper ? v1 : v0) >> ((64 - 2 * jj) & 63);                                                      \
-        /* trailing zeros from column jl - 1 down = 2 * (LEFT moves) + (1 if an UP ends the run) */                        \
-        const int L = x ? __builtin_ctzll(x) : (upper ? 2 * jj + lck_ctz64(v0) : 64);                                      \
-        const int run = min(L >> 1, jl);                                                                                   \
-        wj[H] -= run;                                                                                                      \
-        wrun[H] += run;                                                                                                    \
-        int up = 1;                                           /* at the matrix's left border: UP */                        \
-        bool fin = wj[H] == 0;                                                                                             \
-        if (run < jl) { up = L & 1; fin = true; }                                                                          \
-        (TC) = -1;                                            /* the run goes on in the strip to the left */               \
-        if (fin) {                                                                                                         \
-            SA_LCK_PUSH(H, REC, r0 + t, wrun[H] * 2 + up)                                                                  \
-            wrun[H] = 0;                                                                                                   \
-            if (up == 0) {                                                                                                 \
-                wmatch[H] += (pseq[(H) * P.lslot + wj[H] - 1] == b) ? 1 : 0;                                               \
-                wj[H]--;                                                                                                   \
-            }                                                                                                              \
-            wgaps[H] += up;                                                                                                \
-            wi[H]--;                                                                                                       \
-            if (wj[H] > cbase) (TC) = t - 1;                  /* still in the strip: the row above (-1: the next tile) */  \
-        }                                                                                                                  \
-    }
-#define SA_LCK_ROWSTEP(CH, K)                                                                                              \
-    {                                                                                                                      \
-        const int t = 8 * (CH) + (K);                                                                                      \
-        const uint32_t b = (((K) < 4 ? rx.x : rx.y) >> (8 * ((K) & 3))) & 0xff;                                            \
-        SA_LCK_STEP(0, tc0, a##K##x, rec0)                                                                                 \
-        SA_LCK_STEP(1, tc1, b##K##x, rec1)                                                                                 \
-    }
                     for (int ch = tmax >> 3; ch >= 0; --ch) {
                         if (!__any(tc0 >= 0 || tc1 >= 0)) break;
                         if (timed) tph[7] += 8;
@@ -588,9 +509,6 @@ __device__ __forceinline__ void sa_long_ckpt_body(const SaPepParams& P) {
                         SA_LCK_ROWSTEP(ch, 7) SA_LCK_ROWSTEP(ch, 6) SA_LCK_ROWSTEP(ch, 5) SA_LCK_ROWSTEP(ch, 4)
                         SA_LCK_ROWSTEP(ch, 3) SA_LCK_ROWSTEP(ch, 2) SA_LCK_ROWSTEP(ch, 1) SA_LCK_ROWSTEP(ch, 0)
                     }
-#undef SA_LCK_ROWSTEP
-#undef SA_LCK_STEP
-#undef SA_LCK_FETCH
                     in0 = wi[0] > 0 && wj[0] > cbase;
                     in1 = wi[1] > 0 && wj[1] > cbase;
                     __syncthreads();      // the tile area is free for the next tile
@@ -613,7 +531,6 @@ __device__ __forceinline__ void sa_long_ckpt_body(const SaPepParams& P) {
                         *reinterpret_cast<uint4*>(rec + o) = make_uint4(0, 0, 0, 0);
                 }
             }
-#undef SA_LCK_PUSH
             SA_PHASE(4);
         }
     }

@@ -18,6 +18,7 @@
 // dword per row: a strip only uses a border value minus its base, a difference below 2^12 that the low 16 bits give
 // whatever the whole values are (they pass 2^16 for sequences of a few thousand residues).
 #include "sa_pair_common.h"
+#include "sa_long_walk.h"
 
 #define SA_LONG_PAIR_PROF_STRIDE SA_PAIR_PROF_STRIDE(16)   /* 66 dwords; the LDS is sized for 68 (SA_LDS_PROF_BYTES) */
 #include "sa_traceback.h"
@@ -237,150 +238,55 @@ __device__ __forceinline__ void sa_long_pair_body(const SaPepParams& P) {
             }
             SA_PHASE(3);
 
-            // --------------------------------------------------------- traceback, one half after the other
-            // One row per step, bottom row first, eight rows per 16-byte piece of the record.  The tags of a row
-            // are requested eight rows ahead (see `request` below); the row residues come as two dwords a piece ahead;
-            // the first sequence is read from its LDS copy.  Tag layout: column c of a strip at bits 2(15 - c%16) of
-            // dword c/16.
-#pragma unroll 1
-            for (int half = 0; half < 2; half++) {
-                const bool act = half ? active2 : active;
-                if (!__any(act)) continue;
+            // --------------------------------------------------------- traceback: strip by strip from the right, both
+            // halves side by side, eight rows per request (sa_long_walk.h).  A lane whose path is not in the strip, or
+            // stands above the rows of a request, takes no part in it (and fetches nothing); a run of LEFT moves that
+            // reaches a strip's left edge goes on in the next strip.
+            {
+                int wi[2] = {active ? lenq : 0, active2 ? lenq : 0};
+                int wj[2] = {lenp1, lenp2};
+                int wrun[2] = {0, 0}, wmatch[2] = {0, 0}, wgaps[2] = {0, 0};
+                uint32_t wacc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+                uint8_t* const rec0 = out_row1 + (size_t)(fiq - p1 - 1) * P.stride;
+                uint8_t* const rec1 = out_row2 + (size_t)(fiq - p2 - 1) * P.stride;
 #ifdef SA_LONG_NO_TB
-                continue;
+                wi[0] = wi[1] = 0;       // experiment: the fill alone (records are wrong)
 #endif
-                const int lenp = half ? lenp2 : lenp1;
-                const int lq = act ? lenq : 0;
-                const int mlen = wave_max_nonneg(lq);
-                const uint32_t* hd = dirs + (half ? half_dirs : 0);
-                const uint8_t* ps = pseq + (half ? P.lslot : 0);
-                uint8_t* rec = (half ? out_row2 : out_row1) + (size_t)(fiq - (half ? p2 : p1) - 1) * P.stride;
-                int j = lenp, matches = 0, gaps = 0;
-                auto load_tags = [&](int sj, int r) -> uint4 {
-                    return *reinterpret_cast<const uint4*>(hd + (((size_t)sj * dir_rows + min(max(r, 0), (int)dir_rows - 1)) * 64 + lane) * 4);
-                };
-                // Requests.  The tags of a row are asked for eight rows before the walk gets there, for the strip the lane
-                // stands in at that moment (ra) and -- when the lane is within `margin` columns of that strip's left edge --
-                // for the strip to its left (rb; elsewhere rb repeats ra's address: a request that costs no traffic keeps
-                // the number of requests per row the same for every wave).  Every row issues exactly two loads and the row
-                // code below contains none, so the compiler's waits are counts ("all but the youngest fourteen"), not
-                // "everything": with a load inside the row code -- a second guess taken on the spot -- every row of every
-                // wave waited for the request it had just sent, a full trip to memory per row.
-                // rs: 2 * (strip of ra) + (1 if rb holds the strip to its left).
-                uint4 ra[8], rb[8];
-                int rs[8];
-                // columns the walk is expected to cover in eight rows, with room to spare
-                const int margin = min(64, (12 * lenp) / max(lq, 1) + 16);
-                auto request = [&](int slot, int r) {
-                    const int jc = max(j, 1) - 1;
-                    const int sn = jc >> 6;
-                    const bool wb = sn > 0 && (jc & 63) < margin;
-                    ra[slot] = load_tags(sn, r);
-                    rb[slot] = load_tags(wb ? sn - 1 : sn, r);
-                    rs[slot] = 2 * sn + (wb ? 1 : 0);
-                };
-                const int ch0 = (mlen - 1) >> 3;
-#pragma unroll
-                for (int k = 0; k < 8; k++) request(k, 8 * ch0 + k);
-                uint2 resq = *reinterpret_cast<const uint2*>(bslot + min(8 * ch0, last_row - 7));
-                // One row with loads of its own, for every lane of the wave: the run may go through any number of strips.
-                auto row_by_loads = [&](int r, uint32_t b, int& code) {
-                    int run_total = 0, t = 1;
-                    while (j > 0) {
-                        // L = trailing zeros from column j-1 down = 2 * (LEFT moves) + (1 if an UP ends the run)
-                        const int sj = (j - 1) >> 6, jl = ((j - 1) & 63) + 1;
-                        const uint4 d = load_tags(sj, r);
-                        const uint64_t v0 = ((uint64_t)d.x << 32) | d.y;
-                        const uint64_t v1 = ((uint64_t)d.z << 32) | d.w;
-                        const bool upper = jl > 32;
-                        const int jj = upper ? jl - 32 : jl;
-                        const uint64_t x = (upper ? v1 : v0) >> ((64 - 2 * jj) & 63);
-                        const int tz0 = v0 ? __builtin_ctzll(v0) : 64;
-                        const int L = x ? __builtin_ctzll(x) : (upper ? 2 * jj + tz0 : 64);
-                        const int run = min(L >> 1, jl);
-                        j -= run;
-                        run_total += run;
-                        if (run == jl && j > 0) continue;                     // the run goes on in the strip to the left
-                        if (run < jl) t = L & 1;
-                        break;
+                const int r0 = 0;                                  // the rows on offer are the strip's rows
+                const uint32_t voff = (uint32_t)lane * 16;
+                const uint8_t* const resp = bslot;
+                sa_u32x4v a0x, a1x, a2x, a3x, a4x, a5x, a6x, a7x, b0x, b1x, b2x, b3x, b4x, b5x, b6x, b7x;
+                sa_u32x2v rx;
+                for (int s = nstrips - 1; s >= 0; s--) {
+                    const int cbase = 64 * s;
+                    int tc0 = (wi[0] > 0 && wj[0] > cbase) ? wi[0] - 1 : -1;
+                    int tc1 = (wi[1] > 0 && wj[1] > cbase) ? wi[1] - 1 : -1;
+                    if (!__any(tc0 >= 0 || tc1 >= 0)) continue;
+                    const uint8_t* const tile_a = reinterpret_cast<const uint8_t*>(dirs + (size_t)s * dir_rows * 256);
+                    const uint8_t* const tile_b = tile_a + (size_t)half_dirs * 4;
+                    const int tmax = wave_max_nonneg(max(tc0, tc1) + 1) - 1;
+                    for (int ch = tmax >> 3; ch >= 0; --ch) {
+                        if (!__any(tc0 >= 0 || tc1 >= 0)) break;
+                        SA_LCK_FETCH(ch);
+                        SA_LCK_ROWSTEP(ch, 7) SA_LCK_ROWSTEP(ch, 6) SA_LCK_ROWSTEP(ch, 5) SA_LCK_ROWSTEP(ch, 4)
+                        SA_LCK_ROWSTEP(ch, 3) SA_LCK_ROWSTEP(ch, 2) SA_LCK_ROWSTEP(ch, 1) SA_LCK_ROWSTEP(ch, 0)
                     }
-                    if (t == 0) {
-                        matches += (ps[j - 1] == b) ? 1 : 0;
-                        j--;
-                    }
-                    gaps += t;
-                    code = run_total * 2 + t;
-                };
-                for (int ch = ch0; ch >= 0; --ch) {
-                    uint32_t w[4] = {0, 0, 0, 0};
-                    const uint2 res = resq;
-                    resq = *reinterpret_cast<const uint2*>(bslot + 8 * max(ch - 1, 0));
-#pragma unroll
-                    for (int k = 7; k >= 0; k--) {
-                        const int r = 8 * ch + k;
-                        const bool on = r < lq;
-                        const uint32_t b = ((k < 4 ? res.x : res.y) >> (8 * (k & 3))) & 0xff;
-                        // the row from the tags requested eight rows ago: no load in here
-                        int run_total = 0, t = 1;
-                        bool redo = false;
-                        if (on && j > 0) {
-                            const int sj = (j - 1) >> 6, jl = ((j - 1) & 63) + 1;
-                            const int sa = rs[k] >> 1;
-                            const bool hasb = rs[k] & 1;
-                            const bool from_a = sj == sa, from_b = hasb && sj == sa - 1;
-                            redo = !(from_a || from_b);
-                            const uint4 d = from_a ? ra[k] : rb[k];
-                            const uint64_t v0 = ((uint64_t)d.x << 32) | d.y;
-                            const uint64_t v1 = ((uint64_t)d.z << 32) | d.w;
-                            const bool upper = jl > 32;
-                            const int jj = upper ? jl - 32 : jl;
-                            const uint64_t x = (upper ? v1 : v0) >> ((64 - 2 * jj) & 63);
-                            const int tz0 = v0 ? __builtin_ctzll(v0) : 64;
-                            const int L = x ? __builtin_ctzll(x) : (upper ? 2 * jj + tz0 : 64);
-                            const int run = min(L >> 1, jl);
-                            run_total = run;
-                            if (run < jl) {
-                                t = L & 1;
-                            } else if (j - run > 0) {
-                                // the run goes on in the strip to the left: rb has it, or the row is done again by loads
-                                if (from_a && hasb) {
-                                    const uint64_t e0 = ((uint64_t)rb[k].x << 32) | rb[k].y;
-                                    const uint64_t e1 = ((uint64_t)rb[k].z << 32) | rb[k].w;
-                                    const int L2 = e1 ? __builtin_ctzll(e1) : 64 + (e0 ? __builtin_ctzll(e0) : 64);
-                                    const int run2 = min(L2 >> 1, 64);
-                                    run_total = run + run2;
-                                    if (run2 < 64) t = L2 & 1;
-                                    else if (j - run_total > 0) redo = true;
-                                } else {
-                                    redo = true;
-                                }
-                            }
-                        }
-                        int code = 0;
-                        if (__any(redo)) {
-                            if (on) row_by_loads(r, b, code);
-                        } else if (on) {
-                            j -= run_total;
-                            if (t == 0) {
-                                matches += (ps[j - 1] == b) ? 1 : 0;
-                                j--;
-                            }
-                            gaps += t;
-                            code = run_total * 2 + t;
-                        }
-                        w[k >> 1] |= (uint32_t)code << (16 * (k & 1));
-                        // the same row of the next piece, for the strip the walk is in now
-                        request(k, r - 8);
-                    }
-                    if (act)
-                        *reinterpret_cast<uint4*>(rec + SA_LONG_HEADER_BYTES + 16 * ch) = make_uint4(w[0], w[1], w[2], w[3]);
                 }
-                if (act) {
-                    const int score = (half ? dfin2 : dfin1) + (lenp + lenq) * P.gap;
-                    *reinterpret_cast<uint4*>(rec) = make_uint4((uint32_t)score, (uint32_t)matches, (uint32_t)gaps, 0u);
-                    // rows past the last chunk are zero, so that equal inputs give equal records
-                    for (uint32_t o = SA_LONG_HEADER_BYTES + 16 * (((mlen - 1) >> 3) + 1); o < P.stride; o += 16)
-                        *reinterpret_cast<uint4*>(rec + o) = make_uint4(0, 0, 0, 0);
+                // what is left of a path at the matrix's left border goes straight up; then header and zero tail
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const bool act = h ? active2 : active;
+                    uint8_t* const rec = h ? rec1 : rec0;
+                    if (act) {
+                        for (int r = wi[h] - 1; r >= 0; r--) SA_LCK_PUSH(h, rec, r, 1)
+                        wgaps[h] += wi[h];
+                        const int lenp = h ? lenp2 : lenp1;
+                        const int score = (h ? dfin2 : dfin1) + (lenp + lenq) * P.gap;
+                        *reinterpret_cast<uint4*>(rec) = make_uint4((uint32_t)score, (uint32_t)wmatch[h], (uint32_t)wgaps[h], 0u);
+                        // rows past the last one are zero, so that equal inputs give equal records
+                        for (uint32_t o = SA_LONG_HEADER_BYTES + 2 * (((uint32_t)lenq + 7u) & ~7u); o < P.stride; o += 16)
+                            *reinterpret_cast<uint4*>(rec + o) = make_uint4(0, 0, 0, 0);
+                    }
                 }
             }
             __syncthreads();
