@@ -414,3 +414,41 @@ def test_compact_record_arithmetic_without_a_device():
         assert al.compact_bytes(sa.ADJACENT, 0, n - 1) == at
         assert al.compact_bytes(sa.ADJACENT, 5, 9) == sum(size[6:10])
         al.close()
+
+
+def test_lazy_tables_built_once_under_concurrent_queries():
+    """The per-sequence tables behind sa_cell_count / sa_shard_rows / sa_compact_bytes are built on first use, not at
+    upload: eight threads asking at once straight after an upload (ctypes drops the GIL, so they really do run together)
+    must all see finished tables and the answers a single thread gets."""
+    import random
+    import threading
+    rng = random.Random(11)
+    seqs = ["".join(rng.choice("ACDEFGHIKLMNPQRSTVWY") for _ in range(rng.randint(1, 64))) for _ in range(3000)]
+    n = len(seqs)
+    ref = sa.Aligner(device=sa.DEVICE_NONE)
+    ref.upload(seqs)
+    want = (ref.cell_count(sa.TRIANGULAR, 0, n - 1), ref.compact_bytes(sa.TRIANGULAR, 0, n - 1),
+            ref.compact_bytes(sa.ADJACENT, 0, n - 1), list(ref.shard_rows(sa.TRIANGULAR, 8)))
+    ref.close()
+    for _ in range(5):
+        al = sa.Aligner(device=sa.DEVICE_NONE)
+        al.upload(seqs)
+        got, start = [None] * 8, threading.Barrier(8)
+
+        def ask(k):
+            start.wait()
+            if k % 2:
+                got[k] = (al.cell_count(sa.TRIANGULAR, 0, n - 1), al.compact_bytes(sa.TRIANGULAR, 0, n - 1),
+                          al.compact_bytes(sa.ADJACENT, 0, n - 1), list(al.shard_rows(sa.TRIANGULAR, 8)))
+            else:
+                s = list(al.shard_rows(sa.TRIANGULAR, 8))
+                got[k] = (al.cell_count(sa.TRIANGULAR, 0, n - 1), al.compact_bytes(sa.TRIANGULAR, 0, n - 1),
+                          al.compact_bytes(sa.ADJACENT, 0, n - 1), s)
+
+        threads = [threading.Thread(target=ask, args=(k,)) for k in range(8)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert all(g == want for g in got)
+        al.close()
