@@ -535,7 +535,8 @@ extern "C" unsigned sa_coop_wg_lds_bytes(unsigned lslot, int waves) { return sa_
 // waves = 2, 4, 8 or 16 waves per pair
 extern "C" void sa_launch_coop_wg(int waves, const SaPepParams* p, unsigned grid, hipStream_t stream) {
     const unsigned lds = sa_cwg_lds_bytes(p->lslot, (uint32_t)waves);
-    // more than 64 KiB of dynamic LDS has to be asked for (per device, so at every launch; a refusal shows at the launch)
+    // dynamic LDS beyond the default ceiling (64 KiB) has to be asked for; asked from 48 KiB up to stay clear of it
+    // (per device, so at every launch; a refusal shows at the launch)
     if (lds > 48u * 1024u) {
         const void* f = waves == 2 ? (const void*)sa_coop_wg_kernel<2> : waves == 4 ? (const void*)sa_coop_wg_kernel<4>
                       : waves == 8 ? (const void*)sa_coop_wg_kernel<8> : (const void*)sa_coop_wg_kernel<16>;
