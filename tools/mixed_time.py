@@ -19,7 +19,7 @@ for extra, lo, hi in ((0, 0, 0), (20, 80, 120), (20, 300, 1000), (200, 300, 1000
     try:
         al.prepare_resident(sa.TRIANGULAR, 0, rows)
     except sa.SaError as e:      # the records of every pair at the stride of the longest sequence do not fit the card
-        print("20000 peptides + %d of %d-%d residues: %d-byte records, %s" % (extra, lo, hi, al.stride(), e), flush=True)
+        print("20000 peptides + %d of %d-%d residues: %d-byte records, %s" % (extra, lo, hi, al.stride, e), flush=True)
         al.close()
         continue
     al.run_resident()
