@@ -191,6 +191,13 @@ int sa_set_bucket_width(sa_ctx* ctx, uint32_t width);
  * and longest sequence * max(S - 2*gap) <= 1983 when no sequence exceeds 64 residues; 1 .. 24 otherwise).  enable = 0 forces one first
  * sequence per wave, 32-bit cells (same results; for comparisons and tests).  Default: enabled. */
 int sa_set_pairing(sa_ctx* ctx, int enable);
+/* A set with sequences of more than 64 residues runs on the long-sequence kernels and its records have the long form.
+ * Where such a set also holds peptides, the TRIANGULAR tiles whose sequences all have at most 64 residues are handed to
+ * the paired peptide kernel (writing the same long-form records, byte for byte): the reference treats every pair alike
+ * (include/seqalign.h:13-113), here a few long sequences among peptides must not cost the peptides their kernel.
+ * enable = 0 keeps every tile on the long-sequence kernel (same results; for comparisons and tests).  Default: enabled;
+ * without effect when pairing is off or the table does not fit the packed peptide cells. */
+int sa_set_peptide_tiles(sa_ctx* ctx, int enable);
 /* Sequences longer than 64 residues on the packed TRIANGULAR kernel: how the traceback gets its directions.  The
  * reference keeps the whole score matrix of a pair and walks it (include/seqalign.h:18,63-88).  rows = 64 (default) or
  * 32: the fill keeps values only and leaves a checkpoint (one matrix row per strip) every `rows` rows plus the last

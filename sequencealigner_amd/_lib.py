@@ -140,6 +140,7 @@ SIGNATURES = {
     "sa_last_kernel": (C.c_char_p, [C.c_void_p]),
     "sa_last_grid": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "sa_set_pairing": (C.c_int, [C.c_void_p, C.c_int]),
+    "sa_set_peptide_tiles": (C.c_int, [C.c_void_p, C.c_int]),
     "sa_set_cooperative": (C.c_int, [C.c_void_p, C.c_int]),
     "sa_set_cooperative_waves": (C.c_int, [C.c_void_p, C.c_int]),
     "sa_set_long_checkpoint_rows": (C.c_int, [C.c_void_p, C.c_uint32]),
@@ -343,6 +344,10 @@ class Aligner:
         _check(self._lib.sa_set_pairing(self._ctx, 1 if enable else 0))
 
     # -- dispatch
+    def set_peptide_tiles(self, enable):
+        """Sets with long sequences and peptides: peptide-only tiles on the peptide kernel (default) or not."""
+        _check(self._lib.sa_set_peptide_tiles(self._ctx, 1 if enable else 0))
+
     def submit(self, schedule, r0, r1):
         _check(self._lib.sa_submit(self._ctx, schedule, r0, r1))
 

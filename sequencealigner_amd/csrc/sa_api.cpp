@@ -12,6 +12,7 @@
 #include <memory>
 #include <mutex>
 #include <new>
+#include <string>
 #include <vector>
 #include <time.h>
 
@@ -31,6 +32,7 @@ extern "C" void sa_launch_long_pair(int wide, const SaPepParams* p, unsigned gri
 extern "C" void sa_launch_long_ckpt(int ck_rows, int wide, const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream);
 extern "C" void sa_launch_coop(const SaPepParams* p, unsigned grid, hipStream_t stream);
 extern "C" void sa_launch_coop_wg(int waves, const SaPepParams* p, unsigned grid, hipStream_t stream);
+extern "C" void sa_launch_peptide_pair_longrec(int ng, int wide, const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream);
 extern "C" unsigned sa_coop_wg_lds_bytes(unsigned lslot, int waves);
 extern "C" void sa_launch_long(int mode, const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream);
 extern "C" void sa_launch_compact(int schedule, const uint8_t* out, uint8_t* packed, const uint64_t* cp, const uint64_t* cq,
@@ -103,6 +105,7 @@ struct Work {                 // one submitted (or prepared) row range
     PinBuf host;
     hipEvent_t kernel_done = nullptr, copied = nullptr, t0 = nullptr, t1 = nullptr;
     uint32_t nitems = 0;
+    uint32_t nshort = 0;      // the last nshort items are peptide tiles of a long-sequence context (build_items)
     int schedule = 0;
     uint64_t first_pair = 0, npairs = 0;
     bool busy = false;
@@ -144,6 +147,10 @@ struct sa_ctx {
     uint32_t ckpt_rows = 64;           // paired long-sequence kernel in use: rows between checkpoints (32 or 64); 0 = the kernel that stores a whole direction matrix
     bool ckpt_auto = true;             // ckpt_rows follows the longest uploaded sequence (sa_upload) until sa_set_long_checkpoint_rows names a value
     uint32_t bucket_width_forced = 0;  // sa_set_bucket_width: 0 = from the number of sequences per length
+    bool peptide_tiles = true;         // sa_set_peptide_tiles: in a set with long sequences, tiles of peptides alone run on the peptide kernel
+    uint32_t short_buckets = 0;        // long-sequence contexts with peptides in them: the first short_buckets length buckets are the peptides'
+    uint32_t short_width = 1;          // ... their width in residues (bucket_width: that of the buckets from 65 residues up)
+    uint32_t short_max = 0;            // ... and the longest sequence in them
     // sequences (host mirror)
     uint64_t nseq = 0;
     std::vector<uint16_t> len;         // file order
@@ -179,6 +186,7 @@ struct sa_ctx {
     Work resident;
     bool resident_ready = false;
     const char* last_kernel = "";      // name of the fill + traceback kernel of the most recent launch
+    std::string last_kernel_both;      // ... when there were two (long sequences + peptide tiles): "a + b"
     uint32_t last_grid = 0, last_grid_wanted = 0;    // its workgroups, and how many it would have had with memory to spare
 };
 
@@ -274,6 +282,13 @@ inline uint64_t compact_offset(const sa_ctx* c, int schedule, uint64_t i, uint64
     return c->cq[i] + c->cp[j] - c->cp[i + 1];
 }
 
+// length bucket of a sequence (see ensure_triangular)
+uint32_t bucket_of_length(const sa_ctx* c, uint32_t len) {
+    if (c->short_buckets == 0) return (len - c->min_seq) / c->bucket_width;
+    if (len <= SA_LP) return (len - c->min_seq) / c->short_width;
+    return c->short_buckets + (len - (SA_LP + 1)) / c->bucket_width;
+}
+
 int ensure_triangular(sa_ctx* c) {
     if (c->tri_ready) return SA_OK;
     const uint64_t n = c->nseq;
@@ -285,22 +300,44 @@ int ensure_triangular(sa_ctx* c) {
         SA_HIP_TRY(hipMemcpy(c->slots_host.data(), c->d_codes.p, c->slots_host.size(), hipMemcpyDeviceToHost));
     }
     // length buckets: exact lengths when every length has plenty of sequences, wider otherwise
-    const uint32_t range = c->max_seq - c->min_seq + 1;
-    uint32_t width = (uint32_t)((256ull * range + n - 1) / n);
-    width = std::max(1u, std::min(width, 64u));
     // long sequences: about 48 sequences per bucket, at least 8 residues wide (2 000 proteins of 300-1000 residues: 97.2 ms
     // at 16 residues against 100.8 at 64; 10 000: flat between 8 and 18) -- a wave's rows run to its longest second
     // sequence, and a wave takes its 64 lanes across bucket borders anyway
-    if (c->lslot > SA_LP) width = std::max(8u, std::min((uint32_t)((48ull * range + n - 1) / n), 64u));
-    if (c->bucket_width_forced) width = std::max(1u, std::min(c->bucket_width_forced, std::max(range, 1u)));
-    const uint32_t nb = (range + width - 1) / width;
+    auto peptide_width = [&](uint32_t range, uint64_t count) {
+        return std::max<uint32_t>(1u, (uint32_t)std::min<uint64_t>((256ull * range + count - 1) / count, 64u));
+    };
+    auto long_width = [&](uint32_t range, uint64_t count) {
+        return std::max<uint32_t>(8u, (uint32_t)std::min<uint64_t>((48ull * range + count - 1) / count, 64u));
+    };
+    auto forced = [&](uint32_t width, uint32_t range) {
+        return c->bucket_width_forced ? std::max(1u, std::min(c->bucket_width_forced, std::max(range, 1u))) : width;
+    };
+    // A set with sequences on both sides of 64 residues has two runs of buckets: the peptides' (widths as in a peptide
+    // context) and, from 65 residues up, the long sequences'.  No bucket mixes the two kinds (see build_items).
+    uint64_t npep = 0;
+    if (c->lslot > SA_LP && c->min_seq <= SA_LP)
+        for (uint64_t s = 0; s < n; s++) npep += c->len[s] <= SA_LP;
+    uint32_t width, nb;
+    if (npep) {
+        const uint32_t range1 = SA_LP - c->min_seq + 1, range2 = c->max_seq - SA_LP;
+        c->short_width = forced(peptide_width(range1, npep), range1);
+        c->short_buckets = (range1 + c->short_width - 1) / c->short_width;
+        width = forced(long_width(range2, n - npep), range2);
+        nb = c->short_buckets + (range2 + width - 1) / width;
+    } else {
+        const uint32_t range = c->max_seq - c->min_seq + 1;
+        width = forced(c->lslot > SA_LP ? long_width(range, n) : peptide_width(range, n), range);
+        c->short_width = width;
+        c->short_buckets = 0;
+        nb = (range + width - 1) / width;
+    }
     if ((uint64_t)nb * n > (1ull << 28)) return SA_ERR_NOMEM;   // cursor table of more than 1 GiB
     c->nb = nb;
     c->bucket_width = width;
     std::vector<uint32_t> count(nb + 1, 0);
     std::vector<uint16_t> bucket_of(n);
     for (uint64_t s = 0; s < n; s++) {
-        bucket_of[s] = (uint16_t)((c->len[s] - c->min_seq) / width);
+        bucket_of[s] = (uint16_t)bucket_of_length(c, c->len[s]);
         count[bucket_of[s] + 1]++;
     }
     c->bucket_base.assign(nb + 1, 0);
@@ -310,7 +347,11 @@ int ensure_triangular(sa_ctx* c) {
     std::vector<uint16_t> len_sorted(c->npad, 0);
     std::vector<uint8_t> codes_t((size_t)c->lslot * c->npad, SA_PAD_CODE);
     const bool lng = c->lslot > SA_LP;
-    std::vector<uint8_t> codes_s(lng ? 16 : (size_t)c->npad * SA_LP, SA_PAD_CODE);
+    // Long-sequence contexts: the buckets whose sequences all have at most 64 residues ("peptide buckets") keep the
+    // piece-major copy as well, for the tiles that run on the peptide kernel (build_items).
+    c->short_max = 0;
+    const bool pieces = !lng || c->short_buckets > 0;
+    std::vector<uint8_t> codes_s(pieces ? (size_t)c->npad * SA_LP : 16, SA_PAD_CODE);
     std::vector<uint32_t> fill(c->bucket_base.begin(), c->bucket_base.end() - 1);
     c->cursor.assign((size_t)n * nb, 0);
     std::vector<uint32_t> running(nb, 0);
@@ -321,9 +362,11 @@ int ensure_triangular(sa_ctx* c) {
         len_sorted[slot] = c->len[s];
         const uint8_t* src = c->slots_host.data() + (size_t)s * c->lslot;
         for (uint32_t i = 0; i < c->len[s]; i++) codes_t[(size_t)i * c->npad + slot] = src[i];
-        if (!lng)      // 16-byte pieces, piece-major: piece j of bucket-order slot q at (j * npad + q) * 16
+        if (pieces && c->len[s] <= SA_LP) {      // 16-byte pieces, piece-major: piece j of bucket-order slot q at (j * npad + q) * 16
             for (uint32_t i = 0; i < c->len[s]; i += 16)
                 memcpy(&codes_s[((size_t)(i >> 4) * c->npad + slot) * 16], src + i, std::min<uint32_t>(16, c->len[s] - i));
+            if (b < c->short_buckets) c->short_max = std::max<uint32_t>(c->short_max, c->len[s]);
+        }
         running[b]++;
         memcpy(&c->cursor[(size_t)s * nb], running.data(), nb * sizeof(uint32_t));
     }
@@ -353,13 +396,25 @@ bool is_long(const sa_ctx* c) { return c->lslot > SA_LP; }
 // TRIANGULAR work of a peptide context runs on the paired kernel (two first sequences per wave)
 bool uses_pairs(const sa_ctx* c) { return c->pairing && packed_cells_fit(c, is_long(c)); }
 
+// A long-sequence context whose shortest buckets hold peptides only hands their tiles to the paired peptide kernel
+// (in its long-record form), if the table fits that kernel's cells; sa_set_peptide_tiles(ctx, 0) keeps every tile on
+// the long-sequence kernel.
+bool peptide_tiles_possible(const sa_ctx* c) {
+    return is_long(c) && c->peptide_tiles && c->pairing && c->short_buckets > 0 && packed_cells_fit(c, false);
+}
+
 // paired (in/out): the caller allows the paired kernel / the items were built for it.  A row range in which
 // fewer than half of the first sequences find a partner of their length bucket runs unpaired: a wave of
 // the paired kernel with one first sequence does half the work for the same time.
 uint32_t grid_for(const sa_ctx* c);
 
-int build_items(sa_ctx* c, int schedule, uint64_t r0, uint64_t r1, std::vector<SaItem>& items, bool& paired) {
+// nshort (out, optional): how many items at the END of the list are tiles of peptides alone inside a long-sequence
+// context (peptide_tiles_possible); they run on the peptide kernel.
+bool peptide_tiles_possible(const sa_ctx* c);
+int build_items(sa_ctx* c, int schedule, uint64_t r0, uint64_t r1, std::vector<SaItem>& items, bool& paired,
+                uint32_t* nshort = nullptr) {
     items.clear();
+    if (nshort) *nshort = 0;
     SaItem it;
     memset(&it, 0, sizeof(it));
     if (schedule == SA_SCHEDULE_ADJACENT) {
@@ -388,12 +443,30 @@ int build_items(sa_ctx* c, int schedule, uint64_t r0, uint64_t r1, std::vector<S
         }
     }
     const uint32_t nb = c->nb;
+    // A set with long sequences and peptides: the tiles whose three sequences (the one or two first sequences and every
+    // lane's second sequence) have at most 64 residues are kept apart.  A first sequence's valid list runs through the
+    // buckets from the shortest up, so those tiles are the whole tiles at its start that end inside the peptide buckets.
+    struct ShortRun { uint32_t p, p2, tiles; };
+    std::vector<ShortRun> short_runs;
+    const bool split = is_long(c) && peptide_tiles_possible(c);
+    uint64_t short_tiles = 0;
     // items of first sequence p (and, in the paired kernel, of a second one p2 > p that rides along)
     auto emit = [&](uint64_t p, uint32_t p2) {
         const uint32_t nvalid = (uint32_t)(c->nseq - 1 - p);
         const uint32_t* cur = &c->cursor[(size_t)p * nb];
         uint32_t b = 0, cum = 0;
-        for (uint32_t v0 = 0; v0 < nvalid; v0 += per * 64) {
+        uint32_t first_v0 = 0;
+        if (split && c->len[p] <= SA_LP && (p2 == SA_INVALID_FI || c->len[p2] <= SA_LP)) {
+            uint32_t in_short = 0;
+            for (uint32_t k = 0; k < c->short_buckets; k++) in_short += c->bucket_base[k + 1] - c->bucket_base[k] - cur[k];
+            const uint32_t tiles = in_short == nvalid ? (nvalid + 63) / 64 : in_short / 64;
+            if (tiles) {
+                short_runs.push_back({(uint32_t)p, p2, tiles});
+                short_tiles += tiles;
+                first_v0 = tiles * 64;
+            }
+        }
+        for (uint32_t v0 = first_v0; v0 < nvalid; v0 += per * 64) {
             // bucket that holds entry v0 of p's valid list
             for (;;) {
                 const uint32_t cnt = c->bucket_base[b + 1] - c->bucket_base[b] - cur[b];
@@ -413,7 +486,7 @@ int build_items(sa_ctx* c, int schedule, uint64_t r0, uint64_t r1, std::vector<S
         // first sequences of the same length bucket go two by two, in file order; the valid list of the
         // earlier one contains the later one's
         order.reserve(r1 - r0);
-        for (uint64_t p = r0; p < r1; p++) order.push_back({(uint32_t)((c->len[p] - c->min_seq) / c->bucket_width), (uint32_t)p});
+        for (uint64_t p = r0; p < r1; p++) order.push_back({bucket_of_length(c, c->len[p]), (uint32_t)p});
         std::sort(order.begin(), order.end());
         size_t partners = 0;
         for (size_t k = 0; k + 1 < order.size();) {
@@ -423,6 +496,34 @@ int build_items(sa_ctx* c, int schedule, uint64_t r0, uint64_t r1, std::vector<S
     } else {
         paired = false;
     }
+    // the peptide tiles, behind the other items: several tiles per item as in a peptide context (one query profile
+    // per item), in the order of their first sequences
+    auto emit_short = [&]() {
+        if (short_runs.empty()) return;
+        const uint64_t want = short_tiles / (std::max<uint64_t>(1, (uint64_t)c->ncu * 16) * 32);
+        uint32_t per_short = 1;
+        while (per_short < 32 && per_short * 2 <= want) per_short *= 2;
+        const size_t before = items.size();
+        for (const ShortRun& r : short_runs) {
+            const uint32_t* cur = &c->cursor[(size_t)r.p * nb];
+            uint32_t b = 0, cum = 0;
+            for (uint32_t t = 0; t < r.tiles; t += per_short) {
+                const uint32_t v0 = t * 64;
+                for (;;) {
+                    const uint32_t cnt = c->bucket_base[b + 1] - c->bucket_base[b] - cur[b];
+                    if (cum + cnt > v0) break;
+                    cum += cnt;
+                    b++;
+                }
+                it.p = r.p; it.v0 = v0;
+                it.count = std::min(per_short, r.tiles - t);
+                it.b0 = b; it.c0 = cum;
+                it.reserved[0] = r.p2;
+                items.push_back(it);
+            }
+        }
+        if (nshort) *nshort = (uint32_t)(items.size() - before);
+    };
     if (!paired) {
         for (uint64_t p = r0; p < r1; p++) emit(p, SA_INVALID_FI);
         // long sequences: items differ a lot in work (first sequences of 300 and of 1000 residues); the
@@ -430,6 +531,7 @@ int build_items(sa_ctx* c, int schedule, uint64_t r0, uint64_t r1, std::vector<S
         if (is_long(c))
             std::stable_sort(items.begin(), items.end(),
                              [c](const SaItem& a, const SaItem& b) { return c->len[a.p] > c->len[b.p]; });
+        emit_short();
         return SA_OK;
     }
     // the partners are found in ascending bucket order; the items go out longest bucket first, so that the
@@ -445,6 +547,7 @@ int build_items(sa_ctx* c, int schedule, uint64_t r0, uint64_t r1, std::vector<S
         }
     }
     for (size_t k = duo.size(); k-- > 0;) emit(duo[k].first, duo[k].second);
+    emit_short();
     return SA_OK;
 }
 
@@ -543,6 +646,10 @@ int ensure_spill(sa_ctx* c, uint32_t grid) {
     return SA_OK;
 }
 
+// dword of the 256-byte queue buffer where the second launch of a submission (peptide tiles) has its head; its status
+// word follows at the same distance as the first one's
+constexpr uint32_t kShortQueueWord = 32;
+
 // queue the kernels of one row range on the compute stream
 int launch_work(sa_ctx* c, Work& w, bool timed) {
     if (w.npairs == 0 || w.nitems == 0) return SA_OK;
@@ -569,6 +676,13 @@ int launch_work(sa_ctx* c, Work& w, bool timed) {
     }
     int rc = w.coop ? SA_OK : ensure_spill(c, grid);
     if (rc) return rc;
+    // peptide tiles of a long-sequence context: their kernel's grid and LDS, and its share of the scratch area (the two
+    // launches follow each other on one stream and use the same area)
+    const uint32_t nlong = w.nitems - w.nshort;
+    const int short_ng = c->short_max <= 52 ? 13 : 16;
+    const uint32_t short_lds = SA_PAIR_LDS_BYTES(short_ng);
+    const uint32_t short_grid = (uint32_t)c->ncu * (std::min<uint32_t>(16, (160u * 1024u) / short_lds) + 1);
+    if (w.nshort && (rc = c->d_spill.reserve((size_t)short_grid * 2 * SA_LP * 1024))) return rc;
     SA_HIP_TRY(hipMemsetAsync(w.counter.p, 0, 256, c->compute));
     SaPepParams P;
     memset(&P, 0, sizeof(P));
@@ -584,7 +698,7 @@ int launch_work(sa_ctx* c, Work& w, bool timed) {
     P.npad = c->npad;
     P.sprime = (const int32_t*)c->d_sprime.p;
     P.items = (const SaItem*)w.items.p;
-    P.nitems = w.nitems;
+    P.nitems = nlong;
     P.counter = (uint32_t*)w.counter.p;
     P.out = (uint8_t*)w.out.p;
     P.stride = c->stride;
@@ -606,7 +720,9 @@ int launch_work(sa_ctx* c, Work& w, bool timed) {
     const bool wide = packed_cells_mode(c, is_long(c)) == kCellsWide;
     P.rebase_mask = std::max<uint32_t>(long_rebase_rows(c, wide ? 4095 : 1983), 4) - 1;
     const bool tri = w.schedule == SA_SCHEDULE_TRIANGULAR;
-    if (w.coop) {
+    if (nlong == 0) {
+        c->last_kernel = "";
+    } else if (w.coop) {
         const int waves = coop_waves_for(c, w.nitems);
         // workgroups in flight per CU: by wave slots, and for several waves per pair by LDS
         uint64_t wg_per_cu = 16 / waves;
@@ -646,17 +762,37 @@ int launch_work(sa_ctx* c, Work& w, bool timed) {
         sa_launch_peptide(tri ? 0 : 1, waves, &P, grid, SA_LDS_FIXED_BYTES, c->compute);
         c->last_kernel = !tri ? "sa_peptide_kernel<1, 2>" : waves == 3 ? "sa_peptide_kernel<0, 3>" : "sa_peptide_kernel<0, 2>";
     }
+    if (w.nshort) {
+        SaPepParams Q = P;
+        Q.items = (const SaItem*)w.items.p + nlong;
+        Q.nitems = w.nshort;
+        Q.counter = (uint32_t*)w.counter.p + kShortQueueWord;      // a queue head and status word of its own
+        Q.spill = (uint32_t*)c->d_spill.p;
+        Q.spill_rows = 2 * SA_LP;
+        Q.phase_cycles = nullptr;
+        const bool short_wide = packed_cells_mode(c, false) == kCellsWide;
+        sa_launch_peptide_pair_longrec(short_ng, short_wide ? 1 : 0, &Q, short_grid, short_lds, c->compute);
+        const char* short_name = short_wide ? (short_ng == 13 ? "sa_peptide_pair_wide_longrec_kernel<13, 4>" : "sa_peptide_pair_wide_longrec_kernel<16, 4>")
+                                            : (short_ng == 13 ? "sa_peptide_pair_longrec_kernel<13, 4>" : "sa_peptide_pair_longrec_kernel<16, 4>");
+        c->last_kernel_both = nlong ? std::string(c->last_kernel) + " + " + short_name : std::string(short_name);
+        c->last_kernel = c->last_kernel_both.c_str();
+    }
     SA_HIP_TRY(hipGetLastError());
     if (timed) SA_HIP_TRY(hipEventRecord(w.t1, c->compute));
     if ((rc = w.status_pin.reserve(16))) return rc;
+    ((uint32_t*)w.status_pin.p)[1] = 0;
     SA_HIP_TRY(hipMemcpyAsync(w.status_pin.p, (const uint32_t*)w.counter.p + SA_STATUS_WORD, 4, hipMemcpyDeviceToHost, c->compute));
+    if (w.nshort)
+        SA_HIP_TRY(hipMemcpyAsync((uint32_t*)w.status_pin.p + 1, (const uint32_t*)w.counter.p + kShortQueueWord + SA_STATUS_WORD, 4,
+                                  hipMemcpyDeviceToHost, c->compute));
     return SA_OK;
 }
 
 // after the launch's stream work is complete: did a kernel refuse to run?
 int launch_status(const Work& w) {
     if (w.npairs == 0 || w.nitems == 0 || !w.status_pin.p) return SA_OK;
-    return *(const uint32_t*)w.status_pin.p ? SA_ERR_KERNEL : SA_OK;
+    const uint32_t* st = (const uint32_t*)w.status_pin.p;
+    return (st[0] | st[1]) ? SA_ERR_KERNEL : SA_OK;
 }
 
 int prepare_work_impl(sa_ctx* c, Work& w, int schedule, uint64_t r0, uint64_t r1, bool need_host);
@@ -676,6 +812,7 @@ int prepare_work_impl(sa_ctx* c, Work& w, int schedule, uint64_t r0, uint64_t r1
     w.first_pair = sa_pair_index(c, schedule, r0);
     w.npairs = sa_pair_count(c, schedule, r0, r1);
     w.coop = use_coop(c, w.npairs);
+    w.nshort = 0;
     if (w.coop) {
         // one pair per item, the most expensive first (cost = strips x steps per strip)
         paired = false;
@@ -696,7 +833,7 @@ int prepare_work_impl(sa_ctx* c, Work& w, int schedule, uint64_t r0, uint64_t r1
             return (uint64_t)((c->len[a.p] + 63) / 64) * (c->len[a.v0] + 63) > (uint64_t)((c->len[b.p] + 63) / 64) * (c->len[b.v0] + 63);
         });
     } else {
-        rc = build_items(c, schedule, r0, r1, items, paired);
+        rc = build_items(c, schedule, r0, r1, items, paired, &w.nshort);
     }
     if (rc) return rc;
     w.schedule = schedule;
@@ -1056,11 +1193,12 @@ int sa_clone_sequences(sa_ctx* dst, sa_ctx* src) {
     }
     if (src->tri_ready) {
         dst->nb = src->nb; dst->npad = src->npad; dst->bucket_width = src->bucket_width;
+        dst->short_buckets = src->short_buckets; dst->short_max = src->short_max; dst->short_width = src->short_width;
         dst->bucket_base = src->bucket_base; dst->fi_sorted = src->fi_sorted; dst->cursor = src->cursor;
         if (dev) {
             const bool lng = src->lslot > SA_LP;
             if ((rc = copy(dst->d_codes_t, src->d_codes_t, (size_t)src->lslot * src->npad))) return rc;
-            if ((rc = copy(dst->d_codes_s, src->d_codes_s, lng ? 16 : (size_t)src->npad * SA_LP))) return rc;
+            if ((rc = copy(dst->d_codes_s, src->d_codes_s, (lng && src->short_buckets == 0) ? 16 : (size_t)src->npad * SA_LP))) return rc;
             if ((rc = copy(dst->d_fi_sorted, src->d_fi_sorted, (size_t)src->npad * 4))) return rc;
             if ((rc = copy(dst->d_len_sorted, src->d_len_sorted, (size_t)src->npad * 2))) return rc;
             if ((rc = copy(dst->d_bucket_base, src->d_bucket_base, src->bucket_base.size() * 4))) return rc;
@@ -1459,6 +1597,14 @@ int sa_set_pairing(sa_ctx* c, int enable) {
 }
 
 const char* sa_last_kernel(const sa_ctx* c) { return c ? c->last_kernel : ""; }
+
+int sa_set_peptide_tiles(sa_ctx* c, int enable) {
+    if (!c) return SA_ERR_ARG;
+    if (c->inflight) return SA_ERR_STATE;
+    c->peptide_tiles = enable != 0;
+    c->resident_ready = false;
+    return SA_OK;
+}
 
 int sa_last_grid(const sa_ctx* c, uint32_t* workgroups, uint32_t* wanted) {
     if (!c || !workgroups || !wanted) return SA_ERR_ARG;

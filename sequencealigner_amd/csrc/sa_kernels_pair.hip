@@ -21,7 +21,11 @@
 #include "sa_traceback.h"
 
 // WIDE: the three-way maxima as two unsigned 16-bit maxima each (sa_pair_common.h): longest sequence * max S' <= 4095.
-template <int NG, bool WIDE>
+// LONGREC: the kernel runs the tiles of peptides inside a set that also holds sequences of more than 64 residues: the
+// file-order slots are P.lslot bytes apart and the records have the long form (16-byte header, two bytes per row,
+// every 16-byte chunk of the stride written, zeros past the rows) -- byte for byte what the long-sequence kernels
+// write for the same pair.
+template <int NG, bool WIDE, bool LONGREC = false>
 __device__ __forceinline__ void sa_peptide_pair_body(const SaPepParams& P) {
     constexpr int NC = 4 * NG;
     constexpr int NACC = (NG + 1) / 2;
@@ -66,8 +70,9 @@ __device__ __forceinline__ void sa_peptide_pair_body(const SaPepParams& P) {
         const int lenp1 = P.len_fo[p1];
         const int lenp2 = has2 ? (int)P.len_fo[p2] : 0;
         {
-            const int a1 = P.codes_fo[(size_t)p1 * SA_LP + lane];
-            const int a2 = has2 ? (int)P.codes_fo[(size_t)p2 * SA_LP + lane] : SA_PAD_CODE;
+            const uint32_t slot_bytes = LONGREC ? P.lslot : (uint32_t)SA_LP;
+            const int a1 = P.codes_fo[(size_t)p1 * slot_bytes + lane];
+            const int a2 = has2 ? (int)P.codes_fo[(size_t)p2 * slot_bytes + lane] : SA_PAD_CODE;
             __syncthreads();   // previous item's readers are done with prof/pcol
             // all forty table values are requested before the first is used: one trip to memory per item, not twenty
             // (the loads of a row's two values used to sit between the previous row's LDS write and its own)
@@ -319,7 +324,34 @@ __device__ __forceinline__ void sa_peptide_pair_body(const SaPepParams& P) {
                 // ------------------------------------------- records, 16 B per lane store
                 uint8_t* const out_row = half ? out_row2 : out_row1;
                 const uint32_t rel = fiq - (half ? p2 : p1) - 1;
-                if (cpr == 4) {
+                if constexpr (LONGREC) {
+                    // header and the eight chunks that can hold rows (64 rows of two bytes): nine chunks per record
+                    for (uint32_t id = lane; id < 64 * 9; id += 64) {
+                        const uint32_t rec = id / 9, ch = id - rec * 9;
+                        const uint32_t rrel = __shfl(rel, rec, 64);
+                        const int ract = __shfl((int)act, rec, 64);
+                        if (ract) {
+                            const uint32_t* const st = stage + rec * SD;
+                            const uint2 b = *reinterpret_cast<const uint2*>(st + 2 * ch);    // ch = 0: score, matches | gaps << 16
+                            sa_u32x4 v;
+                            if (ch == 0) {
+                                v = sa_u32x4{b.x, b.y & 0xffffu, b.y >> 16, 0u};
+                            } else {         // rows 8 (ch - 1) .. + 7: a byte each in the staging area, two bytes in the record
+                                v = sa_u32x4{__builtin_amdgcn_perm(0u, b.x, 0x0c010c00u), __builtin_amdgcn_perm(0u, b.x, 0x0c030c02u),
+                                             __builtin_amdgcn_perm(0u, b.y, 0x0c010c00u), __builtin_amdgcn_perm(0u, b.y, 0x0c030c02u)};
+                            }
+                            __builtin_nontemporal_store(v, reinterpret_cast<sa_u32x4*>(out_row + (uint64_t)rrel * P.stride + ch * 16));
+                        }
+                    }
+                    // the rest of the stride: zeros, one record after the other (the count of chunks is the set's, not the pair's)
+                    const uint64_t actmask = cpr > 9 ? __ballot(act) : 0ull;
+                    for (int rec = 0; rec < 64; rec++) {
+                        if (!((actmask >> rec) & 1ull)) continue;
+                        const uint32_t rrel = __builtin_amdgcn_readlane(rel, rec);
+                        for (uint32_t ch = 9 + lane; ch < cpr; ch += 64)
+                            __builtin_nontemporal_store(sa_u32x4{0u, 0u, 0u, 0u}, reinterpret_cast<sa_u32x4*>(out_row + (uint64_t)rrel * P.stride + ch * 16));
+                    }
+                } else if (cpr == 4) {
                     // 64-byte records (no sequence above 56 residues): four lanes per record, sixteen records per round; the
                     // record's place in the row and whether its pair exists come from its lane in one exchange, and the
                     // staging addresses differ from round to round by a constant.  (With the record index and chunk found
@@ -383,6 +415,16 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_wide_kerne
     sa_peptide_pair_body<NG, true>(P);
 }
 
+// the peptide tiles of a set with long sequences in it (records in the long form)
+template <int NG, int WAVES_PER_SIMD>
+__global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_longrec_kernel(const SaPepParams P) {
+    sa_peptide_pair_body<NG, false, true>(P);
+}
+template <int NG, int WAVES_PER_SIMD>
+__global__ void __launch_bounds__(64, WAVES_PER_SIMD) sa_peptide_pair_wide_longrec_kernel(const SaPepParams P) {
+    sa_peptide_pair_body<NG, true, true>(P);
+}
+
 // ng: 4-column groups the register row holds (13: sequences up to 52 residues, 16: up to 64).  Both fit 128
 // registers, four waves per SIMD; the shorter row leaves room in the LDS for one more workgroup per CU.
 extern "C" void sa_launch_peptide_pair(int ng, int wide, const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream) {
@@ -395,5 +437,19 @@ extern "C" void sa_launch_peptide_pair(int ng, int wide, const SaPepParams* p, u
         hipLaunchKernelGGL((sa_peptide_pair_kernel<13, 4>), dim3(grid), dim3(64), lds_bytes, stream, *p);
     } else {
         hipLaunchKernelGGL((sa_peptide_pair_kernel<16, 4>), dim3(grid), dim3(64), lds_bytes, stream, *p);
+    }
+}
+
+// the same kernels writing long-form records (p->lslot > 64, p->stride >= 160)
+extern "C" void sa_launch_peptide_pair_longrec(int ng, int wide, const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream) {
+    if (wide) {
+        if (ng <= 13)
+            hipLaunchKernelGGL((sa_peptide_pair_wide_longrec_kernel<13, 4>), dim3(grid), dim3(64), lds_bytes, stream, *p);
+        else
+            hipLaunchKernelGGL((sa_peptide_pair_wide_longrec_kernel<16, 4>), dim3(grid), dim3(64), lds_bytes, stream, *p);
+    } else if (ng <= 13) {
+        hipLaunchKernelGGL((sa_peptide_pair_longrec_kernel<13, 4>), dim3(grid), dim3(64), lds_bytes, stream, *p);
+    } else {
+        hipLaunchKernelGGL((sa_peptide_pair_longrec_kernel<16, 4>), dim3(grid), dim3(64), lds_bytes, stream, *p);
     }
 }

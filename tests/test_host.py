@@ -209,6 +209,50 @@ def test_work_items_cover_every_pair_once(n, lo, hi, pairing):
             assert al.cell_count(schedule, r0, r1) == cells
 
 
+def _mixed_set(n, n_long, lo, hi, seed):
+    """n peptides of 6-50 residues with n_long sequences of lo-hi residues spread among them"""
+    seqs, _ = synth.generate(n, 6, 50, seed=seed)
+    more, _ = synth.generate(n_long, lo, hi, seed=seed + 1)
+    step = n // n_long
+    for k, s in enumerate(more):
+        seqs.insert(k * step + k + 3, s)
+    return seqs
+
+
+@pytest.mark.parametrize("n,n_long,lo,hi", [(400, 6, 70, 300), (300, 40, 60, 90), (200, 3, 500, 900)])
+def test_work_items_of_a_set_of_peptides_and_long_sequences(n, n_long, lo, hi):
+    """A set with sequences above 64 residues is a long-sequence context; the tiles whose sequences are all peptides form
+    the end of the work list (several tiles per item, for the peptide kernel).  Every pair still appears exactly once,
+    with the split on and off, and the split takes most of the peptide-against-peptide pairs."""
+    seqs = _mixed_set(n, n_long, lo, hi, seed=n)
+    total = len(seqs)
+    al = sa.Aligner(device=sa.DEVICE_NONE, max_seq_len=hi)
+    al.upload(seqs)
+    assert al.row_bytes == 2
+    order = al.bucket_order().tolist()
+    rows = al.rows(sa.TRIANGULAR)
+    short = [len(x) <= 64 for x in seqs]
+    for tiles_on in (True, False):
+        al.set_peptide_tiles(tiles_on)
+        for r0, r1 in ((0, rows), (rows // 3, rows // 2)):
+            items = al.work_items(sa.TRIANGULAR, r0, r1)
+            got = sorted(_pairs_of_items(items, order, sa.TRIANGULAR))
+            assert got == [(i, j) for i in range(r0, r1) for j in range(i + 1, total)]
+            # the items at the end whose first sequences and entries are all peptides
+            tail_pairs = 0
+            for it in items.tolist()[::-1]:
+                ps = _pairs_of_items(np.array([it], dtype=items.dtype), order, sa.TRIANGULAR)
+                if not all(short[i] and short[j] for i, j in ps):
+                    break
+                tail_pairs += len(ps)
+            peptide_pairs = sum(1 for i, j in got if short[i] and short[j])
+            if tiles_on:
+                assert tail_pairs >= 0.8 * peptide_pairs - 64 * (r1 - r0)
+            else:
+                assert all(it[2] == 1 for it in items.tolist())      # one tile per item, as the long kernels take them
+    al.close()
+
+
 def test_pair_index_is_row_major_triangular():
     seqs, _ = synth.generate(50, 6, 20, seed=5)
     al = sa.Aligner(device=sa.DEVICE_NONE)
