@@ -276,6 +276,33 @@ def resident_measurement(sa, synth, name, device, launches=2, pairing=True, chec
     return out
 
 
+def mixed_lengths_measurement(sa, synth, device):
+    """Peptides with a few long sequences among them: the set is a long-sequence one (kernel, record form and stride
+    follow the longest sequence); the tiles whose sequences are all peptides run on the peptide kernel (on), or every
+    tile on the long-sequence kernel (off)."""
+    out = {}
+    for key, (npep, extra, lo, hi) in {"20000_peptides_plus_20_of_80_120": (20000, 20, 80, 120),
+                                       "8000_peptides_plus_20_of_300_1000": (8000, 20, 300, 1000)}.items():
+        seqs, _ = synth.generate(npep, 6, 50, 3)
+        more, _ = synth.generate(extra, lo, hi, 5)
+        step = len(seqs) // extra
+        for k, s in enumerate(more):
+            seqs.insert(k * step + k, s)
+        al = sa.Aligner(device=device, max_seq_len=hi)
+        al.upload(seqs)
+        rows = al.rows(sa.TRIANGULAR)
+        res = {"pairs": al.pair_count(sa.TRIANGULAR, 0, rows), "cells": al.cell_count(sa.TRIANGULAR, 0, rows), "record_bytes": al.stride}
+        for tiles, name in ((True, "peptide_tiles_on"), (False, "peptide_tiles_off")):
+            al.set_peptide_tiles(tiles)
+            al.prepare_resident(sa.TRIANGULAR, 0, rows)
+            al.run_resident()
+            ms = min(al.run_resident() for _ in range(2))
+            res[name] = {"kernel": al.last_kernel(), "kernel_ms": round(ms, 3), "gcups": round(res["cells"] / ms / 1e6, 1)}
+        al.close()
+        out[key] = res
+    return out
+
+
 def few_pairs_measurement(sa, synth, device):
     """Submissions of few long pairs, where a pair per lane leaves the chip idle: one wave per pair, a workgroup of
     waves per pair (the library picks 1 to 16 waves from the pair count) and the pair-per-lane kernel on 64 adjacent
@@ -601,6 +628,7 @@ def main():
                     extra["proteins10k"] = resident_measurement(sa, synth, "proteins10k", local_rank, launches=1)
                     # between the two regimes: sequences a little longer than the peptide kernel's 64 columns
                     extra["domains16k"] = resident_measurement(sa, synth, "domains16k", local_rank, launches=1)
+                    extra["mixed_lengths"] = mixed_lengths_measurement(sa, synth, local_rank)
                 out["extra"] = extra
                 if args.cpu_sample > 0:
                     out["cpu_baseline"] = cpu_baseline(sa, synth, seqs, labels, min(args.cpu_sample, n) if hi <= 64 else min(300, n),

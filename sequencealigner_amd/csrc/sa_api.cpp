@@ -79,7 +79,9 @@ struct DevBuf {
         if (bytes <= cap) return SA_OK;
         if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return hip_code(e); }
         hipError_t e = hipMalloc(&p, bytes);
-        if (e != hipSuccess) { p = nullptr; return hip_code(e); }
+        // a refused allocation is an answer, not a fault: the runtime's sticky error is taken back, or the next
+        // launch's hipGetLastError would report it
+        if (e != hipSuccess) { p = nullptr; (void)hipGetLastError(); return hip_code(e); }
         cap = bytes;
         return SA_OK;
     }
@@ -93,7 +95,7 @@ struct PinBuf {
         if (bytes <= cap) return SA_OK;
         if (p) { hipError_t e = hipHostFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return hip_code(e); }
         hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
-        if (e != hipSuccess) { p = nullptr; return hip_code(e); }
+        if (e != hipSuccess) { p = nullptr; (void)hipGetLastError(); return hip_code(e); }
         cap = bytes;
         return SA_OK;
     }

@@ -325,31 +325,27 @@ __device__ __forceinline__ void sa_peptide_pair_body(const SaPepParams& P) {
                 uint8_t* const out_row = half ? out_row2 : out_row1;
                 const uint32_t rel = fiq - (half ? p2 : p1) - 1;
                 if constexpr (LONGREC) {
-                    // header and the eight chunks that can hold rows (64 rows of two bytes): nine chunks per record
-                    for (uint32_t id = lane; id < 64 * 9; id += 64) {
-                        const uint32_t rec = id / 9, ch = id - rec * 9;
+                    // Chunk after chunk through the 64 records of the half: consecutive lanes write consecutive 16-byte chunks,
+                    // 1 KiB per store instruction wherever the records follow each other in the row.  Chunk 0 is the header,
+                    // chunks 1-8 can hold rows (64 rows of two bytes), the rest of the stride is zeros.
+                    const uint32_t magic = 0xffffffffu / cpr + 1u;        // id / cpr = id * magic >> 32 for id < 64 * cpr
+                    for (uint32_t id = lane; id < 64 * cpr; id += 64) {
+                        const uint32_t rec = __umulhi(id, magic), ch = id - rec * cpr;
                         const uint32_t rrel = __shfl(rel, rec, 64);
                         const int ract = __shfl((int)act, rec, 64);
                         if (ract) {
-                            const uint32_t* const st = stage + rec * SD;
-                            const uint2 b = *reinterpret_cast<const uint2*>(st + 2 * ch);    // ch = 0: score, matches | gaps << 16
-                            sa_u32x4 v;
-                            if (ch == 0) {
-                                v = sa_u32x4{b.x, b.y & 0xffffu, b.y >> 16, 0u};
-                            } else {         // rows 8 (ch - 1) .. + 7: a byte each in the staging area, two bytes in the record
-                                v = sa_u32x4{__builtin_amdgcn_perm(0u, b.x, 0x0c010c00u), __builtin_amdgcn_perm(0u, b.x, 0x0c030c02u),
-                                             __builtin_amdgcn_perm(0u, b.y, 0x0c010c00u), __builtin_amdgcn_perm(0u, b.y, 0x0c030c02u)};
+                            sa_u32x4 v = {0u, 0u, 0u, 0u};
+                            if (ch <= 8) {
+                                const uint2 b = *reinterpret_cast<const uint2*>(stage + rec * SD + 2 * ch);    // ch = 0: score, matches | gaps << 16
+                                if (ch == 0) {
+                                    v = sa_u32x4{b.x, b.y & 0xffffu, b.y >> 16, 0u};
+                                } else {         // rows 8 (ch - 1) .. + 7: a byte each in the staging area, two bytes in the record
+                                    v = sa_u32x4{__builtin_amdgcn_perm(0u, b.x, 0x0c010c00u), __builtin_amdgcn_perm(0u, b.x, 0x0c030c02u),
+                                                 __builtin_amdgcn_perm(0u, b.y, 0x0c010c00u), __builtin_amdgcn_perm(0u, b.y, 0x0c030c02u)};
+                                }
                             }
                             __builtin_nontemporal_store(v, reinterpret_cast<sa_u32x4*>(out_row + (uint64_t)rrel * P.stride + ch * 16));
                         }
-                    }
-                    // the rest of the stride: zeros, one record after the other (the count of chunks is the set's, not the pair's)
-                    const uint64_t actmask = cpr > 9 ? __ballot(act) : 0ull;
-                    for (int rec = 0; rec < 64; rec++) {
-                        if (!((actmask >> rec) & 1ull)) continue;
-                        const uint32_t rrel = __builtin_amdgcn_readlane(rel, rec);
-                        for (uint32_t ch = 9 + lane; ch < cpr; ch += 64)
-                            __builtin_nontemporal_store(sa_u32x4{0u, 0u, 0u, 0u}, reinterpret_cast<sa_u32x4*>(out_row + (uint64_t)rrel * P.stride + ch * 16));
                     }
                 } else if (cpr == 4) {
                     // 64-byte records (no sequence above 56 residues): four lanes per record, sixteen records per round; the

@@ -124,3 +124,23 @@ def test_peptide_tiles_survive_a_clone_and_a_second_upload():
     assert np.array_equal(al.align(sa.TRIANGULAR), first)
     al.close()
     other.close()
+
+
+def test_a_refused_allocation_leaves_the_context_usable():
+    """The records of every pair at the stride of a 4096-residue sequence do not fit the card: sa_prepare_resident says
+    out of memory, and the calls after it (which size their submissions themselves) work as if nothing had happened."""
+    seqs = _mixed(12000, 66, 70, 1, 4096, 4096, 17)
+    al = sa.Aligner(max_seq_len=4096)
+    al.upload(seqs)
+    rows = al.rows(sa.TRIANGULAR)
+    assert al.pair_count(sa.TRIANGULAR, 0, rows) * al.stride > 400e9
+    with pytest.raises(sa.SaError) as err:
+        al.prepare_resident(sa.TRIANGULAR, 0, rows)
+    assert "memory" in str(err.value)
+    recs = al.align(sa.TRIANGULAR, 0, 2)
+    _check(al, seqs, recs, [(k, (0, k + 1)) for k in range(0, 12000, 1500)])
+    small = _mixed(300, 6, 50, 0, 0, 0, 18)
+    al.upload(small)
+    recs = al.align(sa.TRIANGULAR)
+    _check(al, small, recs, [(k, (0, k + 1)) for k in range(0, 299, 30)])
+    al.close()
