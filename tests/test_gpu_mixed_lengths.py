@@ -75,18 +75,27 @@ def test_peptide_tiles_write_the_long_kernels_records(n, lo, hi, n_long, long_lo
     al.close()
 
 
-def test_peptide_tiles_with_a_table_beyond_the_half_precision_range():
+@pytest.mark.parametrize("gap,kernels", [
+    (-14, "sa_long_pair_wide_kernel<4> + sa_peptide_pair_wide_longrec_kernel<16, 4>"),
+    # S' up to 61: beyond the long kernels' packed cells (32-bit cells, one first sequence per wave), within the peptide kernel's
+    (-23, "sa_long_kernel<0, 2> + sa_peptide_pair_wide_longrec_kernel<16, 4>"),
+])
+def test_peptide_tiles_with_a_table_beyond_the_half_precision_range(gap, kernels):
     """gap -14: S' up to 43, 64 residues x 43 = 2752: the peptide tiles take the wide form, and so do the long kernels."""
     seqs = _mixed(600, 6, 64, 6, 80, 260, 7)
-    al = sa.Aligner(max_seq_len=260, gap=-14)
+    al = sa.Aligner(max_seq_len=260, gap=gap)
     al.upload(seqs)
     al.set_cooperative(-1)
     both = al.align(sa.TRIANGULAR)
-    assert al.last_kernel() == "sa_long_pair_wide_kernel<4> + sa_peptide_pair_wide_longrec_kernel<16, 4>"
+    assert al.last_kernel() == kernels
     al.set_pairing(False)
     plain = al.align(sa.TRIANGULAR)
     assert al.last_kernel() == "sa_long_kernel<0, 2>"
     assert np.array_equal(both, plain)
+    rng = random.Random(gap)
+    total = len(seqs)
+    sample = [(i, rng.randrange(i + 1, total)) for i in (rng.randrange(total - 1) for _ in range(60))]
+    _check(al, seqs, both, [(al.pair_index(sa.TRIANGULAR, i) + j - i - 1, (i, j)) for i, j in sample], gap=gap)
     al.close()
 
 
