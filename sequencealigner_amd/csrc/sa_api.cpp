@@ -225,7 +225,8 @@ enum { kCellsNone = 0, kCellsNarrow = 1, kCellsWide = 2 };
 int packed_cells_mode(const sa_ctx* c, bool lng) {
     if (c->sprime_min < 1) return kCellsNone;
     if (lng) return long_rebase_rows(c, 1983) ? kCellsNarrow : long_rebase_rows(c, 4095) ? kCellsWide : kCellsNone;
-    const int64_t span = std::max<int64_t>(1, std::min<int64_t>(c->max_seq, SA_LP));
+    // (the peptide tiles of a set with long sequences: the longest of its peptides)
+    const int64_t span = std::max<int64_t>(1, c->lslot > SA_LP ? c->short_max : std::min<int64_t>(c->max_seq, SA_LP));
     return span * c->sprime_max <= 1983 ? kCellsNarrow : span * c->sprime_max <= 4095 ? kCellsWide : kCellsNone;
 }
 bool packed_cells_fit(const sa_ctx* c, bool lng) { return packed_cells_mode(c, lng) != kCellsNone; }
