@@ -16,6 +16,8 @@ for npep, extra, lo, hi in ((20000, 0, 0, 0), (20000, 20, 80, 120), (8000, 0, 0,
     rows = al.rows(sa.TRIANGULAR)
     cells = al.cell_count(sa.TRIANGULAR, 0, rows)
     out = []
+    digests = []
+    pairs = al.pair_count(sa.TRIANGULAR, 0, rows)
     for tiles in ((True, False) if extra else (True,)):
         al.set_peptide_tiles(tiles)
         try:
@@ -25,6 +27,9 @@ for npep, extra, lo, hi in ((20000, 0, 0, 0), (20000, 20, 80, 120), (8000, 0, 0,
             break
         al.run_resident()
         ms = min(al.run_resident() for _ in range(2))
+        digests.append(tuple(al.digest_resident(0, pairs)))
         out.append("%s %.1f ms %.0f GCUPS" % (al.last_kernel(), ms, cells / ms / 1e6))
+    if len(digests) == 2:
+        out.append("digests of all %d records %s" % (pairs, "equal" if digests[0] == digests[1] else "DIFFER"))
     print("%d peptides + %d of %d-%d residues, %d-byte records, cells %.2e: %s" % (npep, extra, lo, hi, al.stride, cells, " | ".join(out)), flush=True)
     al.close()
