@@ -153,3 +153,37 @@ def test_a_refused_allocation_leaves_the_context_usable():
     recs = al.align(sa.TRIANGULAR)
     _check(al, small, recs, [(k, (0, k + 1)) for k in range(0, 299, 30)])
     al.close()
+
+
+def test_large_mixed_set_every_record_by_digest():
+    """8 000 peptides with 20 sequences of 80-120 residues among them, resident: all 3.2e7 records, digested on the device,
+    are the same with the peptide tiles on the peptide kernel and with every tile on the long-sequence kernel; sampled
+    pairs against the checker."""
+    seqs, _ = synth.generate(8000, 6, 50, 3)
+    more, _ = synth.generate(20, 80, 120, 5)
+    for k, s in enumerate(more):
+        seqs.insert(k * 400 + k, s)
+    total = len(seqs)
+    al = sa.Aligner(max_seq_len=120)
+    al.upload(seqs)
+    rows = al.rows(sa.TRIANGULAR)
+    pairs = al.pair_count(sa.TRIANGULAR, 0, rows)
+    digests = []
+    for tiles in (True, False):
+        al.set_peptide_tiles(tiles)
+        al.prepare_resident(sa.TRIANGULAR, 0, rows)
+        al.run_resident()
+        assert ("longrec" in al.last_kernel()) == tiles
+        digests.append([al.digest_resident(a, min(4_000_000, pairs - a)) for a in range(0, pairs, 4_000_000)])
+    assert digests[0] == digests[1]
+    al.set_peptide_tiles(True)
+    al.prepare_resident(sa.TRIANGULAR, 0, rows)
+    al.run_resident()
+    rng = random.Random(5)
+    for _ in range(40):
+        i = rng.randrange(total - 1)
+        first = al.pair_index(sa.TRIANGULAR, i)
+        n = min(30, total - 1 - i)
+        recs = al.fetch_resident(first, n)
+        _check(al, [x.decode() if isinstance(x, bytes) else x for x in seqs], recs, [(k, (i, i + 1 + k)) for k in range(0, n, 7)])
+    al.close()
