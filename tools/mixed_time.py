@@ -4,7 +4,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sequencealigner_amd as sa
 from sequencealigner_amd import synth
-for npep, extra, lo, hi in ((20000, 0, 0, 0), (20000, 20, 80, 120), (8000, 0, 0, 0), (8000, 20, 80, 120), (8000, 20, 300, 1000), (8000, 200, 300, 1000)):
+for npep, extra, lo, hi in ((20000, 0, 0, 0), (20000, 20, 80, 120), (20000, 600, 65, 200), (8000, 0, 0, 0), (8000, 20, 80, 120), (8000, 20, 300, 1000), (8000, 200, 300, 1000)):
     seqs, _ = synth.generate(npep, 6, 50, 3)
     if extra:
         more, _ = synth.generate(extra, lo, hi, 5)
