@@ -1628,7 +1628,7 @@ int sa_debug_work_items(sa_ctx* c, int schedule, uint64_t r0, uint64_t r1, uint3
     *count = items.size();
     if (items8) {
         const uint64_t n = std::min<uint64_t>(cap, items.size());
-        memcpy(items8, items.data(), n * sizeof(SaItem));
+        if (n) memcpy(items8, items.data(), n * sizeof(SaItem));
     }
     return SA_OK;
 }
