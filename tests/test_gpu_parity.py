@@ -72,6 +72,25 @@ def test_avpdb_triangular_csv_many_small_chunks(golden_dir, tmp_path, hashes):
     assert sha256_file(out) == hashes["avpdb_triangular_out"]
 
 
+@pytest.mark.parametrize("pairs_per_submit", [0, 30000])
+def test_output_in_a_tmpfs_is_written_through_shared_mappings(golden_dir, hashes, pairs_per_submit):
+    """A file in memory takes its chunks (of a megabyte and more) through mappings filled by several threads, at byte
+    offsets that are not page borders: whole and in 4 MB chunks, the 72 MB of the all-vs-all output have the pinned hash."""
+    import shutil
+    import tempfile
+    if not os.path.isdir("/dev/shm"):
+        pytest.skip("no /dev/shm")
+    d = tempfile.mkdtemp(dir="/dev/shm")
+    try:
+        out = os.path.join(d, "tri.csv")
+        kw = {"pairs_per_submit": pairs_per_submit} if pairs_per_submit else {}
+        rep = sa.run_csv(os.path.join(golden_dir, "avpdb.csv"), out, sa.TRIANGULAR, **kw)
+        assert rep.bytes_written == 72072734
+        assert sha256_file(out) == hashes["avpdb_triangular_out"]
+    finally:
+        shutil.rmtree(d)
+
+
 def test_mega_dataset_csv_hash(golden_dir, tmp_path, hashes):
     mega = tmp_path / "mega.csv"
     synth.make_mega(os.path.join(golden_dir, "avpdb.csv"), str(mega))
