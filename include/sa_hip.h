@@ -198,6 +198,13 @@ int sa_set_pairing(sa_ctx* ctx, int enable);
  * enable = 0 keeps every tile on the long-sequence kernel (same results; for comparisons and tests).  Default: enabled;
  * without effect when pairing is off or the table does not fit the packed peptide cells. */
 int sa_set_peptide_tiles(sa_ctx* ctx, int enable);
+/* Loads the device code a job of this kind will use (slot packing and the peptide kernels; the paired peptide kernel
+ * for TRIANGULAR work of a context whose sequences cannot exceed 64 residues; the row formatter; the record packer)
+ * on the context's device now, instead of at the first launch of each kernel.  Touches no state of the context and may
+ * run on a thread of its own while the caller reads its input -- the CSV driver does that: a fresh process spent 23 ms
+ * of its timed window loading code at first launches.  No counterpart in the reference (its code is loaded with the
+ * program, src/main.c); results do not depend on it. */
+int sa_preload_kernels(sa_ctx* ctx, int schedule, int device_text, int compact_records);
 /* Sequences longer than 64 residues on the packed TRIANGULAR kernel: how the traceback gets its directions.  The
  * reference keeps the whole score matrix of a pair and walks it (include/seqalign.h:18,63-88).  rows = 64 (default) or
  * 32: the fill keeps values only and leaves a checkpoint (one matrix row per strip) every `rows` rows plus the last

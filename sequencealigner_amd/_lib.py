@@ -141,6 +141,7 @@ SIGNATURES = {
     "sa_last_grid": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "sa_set_pairing": (C.c_int, [C.c_void_p, C.c_int]),
     "sa_set_peptide_tiles": (C.c_int, [C.c_void_p, C.c_int]),
+    "sa_preload_kernels": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "sa_set_cooperative": (C.c_int, [C.c_void_p, C.c_int]),
     "sa_set_cooperative_waves": (C.c_int, [C.c_void_p, C.c_int]),
     "sa_set_long_checkpoint_rows": (C.c_int, [C.c_void_p, C.c_uint32]),

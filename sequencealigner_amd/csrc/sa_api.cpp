@@ -32,6 +32,10 @@ extern "C" void sa_launch_long_pair(int wide, const SaPepParams* p, unsigned gri
 extern "C" void sa_launch_long_ckpt(int ck_rows, int wide, const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream);
 extern "C" void sa_launch_coop(const SaPepParams* p, unsigned grid, hipStream_t stream);
 extern "C" void sa_launch_coop_wg(int waves, const SaPepParams* p, unsigned grid, hipStream_t stream);
+extern "C" int sa_load_code_peptide(hipStream_t stream);
+extern "C" int sa_load_code_peptide_pair(void);
+extern "C" int sa_load_code_format(void);
+extern "C" int sa_load_code_compact(void);
 extern "C" void sa_launch_peptide_pair_longrec(int ng, int wide, const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream);
 extern "C" unsigned sa_coop_wg_lds_bytes(unsigned lslot, int waves);
 extern "C" void sa_launch_long(int mode, const SaPepParams* p, unsigned grid, unsigned lds_bytes, hipStream_t stream);
@@ -1600,6 +1604,32 @@ int sa_set_pairing(sa_ctx* c, int enable) {
 }
 
 const char* sa_last_kernel(const sa_ctx* c) { return c ? c->last_kernel : ""; }
+
+int sa_preload_kernels(sa_ctx* c, int schedule, int device_text, int compact_records) {
+    if (!c || (schedule != SA_SCHEDULE_ADJACENT && schedule != SA_SCHEDULE_TRIANGULAR)) return SA_ERR_ARG;
+    if (c->device == SA_DEVICE_NONE) return SA_OK;
+    SA_HIP_TRY(hipSetDevice(c->device));
+    // slot packing, the 32-bit peptide kernels and the digest live in one code object; the rest as the caller says.
+    // The long-sequence kernels are not guessed at: whether a set needs them is known only once it has been read.
+    if (sa_load_code_peptide(c->compute)) { (void)hipGetLastError(); return SA_ERR_HIP; }
+    {
+        // the first copies in either direction set up the runtime's staging buffers and the copy engines' queues
+        DevBuf word;
+        uint32_t zero = 0;
+        if (word.reserve(256) == SA_OK) {
+            (void)hipMemcpyAsync(word.p, &zero, 4, hipMemcpyHostToDevice, c->compute);
+            (void)hipMemcpyAsync(&zero, word.p, 4, hipMemcpyDeviceToHost, c->copy);
+            (void)hipStreamSynchronize(c->compute);
+            (void)hipStreamSynchronize(c->copy);
+            word.release();
+        }
+        (void)hipGetLastError();
+    }
+    if (schedule == SA_SCHEDULE_TRIANGULAR && c->max_len <= SA_LP && c->pairing && sa_load_code_peptide_pair()) { (void)hipGetLastError(); return SA_ERR_HIP; }
+    if (device_text && sa_load_code_format()) { (void)hipGetLastError(); return SA_ERR_HIP; }
+    if (compact_records && sa_load_code_compact()) { (void)hipGetLastError(); return SA_ERR_HIP; }
+    return SA_OK;
+}
 
 int sa_set_peptide_tiles(sa_ctx* c, int enable) {
     if (!c) return SA_ERR_ARG;

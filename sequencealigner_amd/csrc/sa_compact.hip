@@ -64,3 +64,10 @@ extern "C" void sa_launch_compact(int schedule, const uint8_t* out, uint8_t* pac
                                     : dim3((unsigned)((r1 - r0 + 255) / 256));
     hipLaunchKernelGGL(sa_compact_kernel, grid, dim3(256), 0, stream, A);
 }
+
+// Loads this file's code object on the current device without launching anything (the runtime otherwise loads it at
+// the first launch of one of its kernels: milliseconds on the critical path of a short job).
+extern "C" int sa_load_code_compact(void) {
+    hipFuncAttributes a;
+    return (int)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(sa_compact_kernel));
+}

@@ -185,3 +185,10 @@ extern "C" hipError_t sa_launch_format(const SaFormatParams* F, void* scan_tmp, 
     hipLaunchKernelGGL(sa_rows_kernel, dim3(grid), dim3(256), 0, stream, *F);
     return hipGetLastError();
 }
+
+// Loads this file's code object on the current device without launching anything (the runtime otherwise loads it at
+// the first launch of one of its kernels: milliseconds on the critical path of a short job).
+extern "C" int sa_load_code_format(void) {
+    hipFuncAttributes a;
+    return (int)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(sa_rows_kernel));
+}

@@ -465,7 +465,11 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
     // contexts first: like the reference's pool, they are set up outside the timed window (src/main.c:10,30)
     const int ndev = st->num_devices;
     std::vector<sa_ctx*> ctx((size_t)ndev, nullptr);
-    auto cleanup = [&]() { for (auto c : ctx) sa_destroy(c); };
+    std::thread preload;          // loads device code while the input is read (below); joined before anything is destroyed
+    auto cleanup = [&]() {
+        if (preload.joinable()) preload.join();
+        for (auto c : ctx) sa_destroy(c);
+    };
     // the reference's buffers hold sequences shorter than MAX_SEQ_LEN (NUL included, include/thread.h:27-29)
     const uint32_t max_len = st->max_seq_len ? st->max_seq_len - 1 : 0;
     if (max_len == 0 || max_len > SA_MAX_SEQ_LEN) { err = "MAX_SEQ_LEN must be between 2 and 4097"; return fail(SA_ERR_LENGTH); }
@@ -515,6 +519,10 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
 
     const double t0 = now_s();
     double t_format = 0, t_write = 0, t_wait = 0;
+    // The device code this job will launch is loaded while the input is read (a thread of its own: the runtime would
+    // otherwise load each code object at the first launch of one of its kernels, 23 ms of a fresh process's 120 on the
+    // 4 001 280-row data set).  A failure here is not the job's: the launches would report it.
+    preload = std::thread([&]() { (void)sa_preload_kernels(ctx[0], st->schedule, text_mode ? 1 : 0, compact ? 1 : 0); });
     Table tab;
     rc = load_table(st, tab, err);
     if (rc) { cleanup(); if (out_fd >= 0) close(out_fd); return fail(rc); }
@@ -611,6 +619,7 @@ int sa_run_csv(const sa_settings* st, sa_run_report* rep) {
         // The first context takes the sequences from the host (validation, slots, length tables; for TRIANGULAR the
         // bucket order and cursor table; for rows written on the GPU the layout and the pass-through text); the
         // others clone it device to device, all at once.
+        if (preload.joinable()) preload.join();
         rc = sa_upload(ctx[0], codes, offs, lens, n);
         if (rc == SA_OK && text_mode) {
             sa_text_layout tl;

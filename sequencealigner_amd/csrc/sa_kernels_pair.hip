@@ -449,3 +449,10 @@ extern "C" void sa_launch_peptide_pair_longrec(int ng, int wide, const SaPepPara
         hipLaunchKernelGGL((sa_peptide_pair_longrec_kernel<16, 4>), dim3(grid), dim3(64), lds_bytes, stream, *p);
     }
 }
+
+// Loads this file's code object on the current device without launching anything (the runtime otherwise loads it at
+// the first launch of one of its kernels: milliseconds on the critical path of a short job).
+extern "C" int sa_load_code_peptide_pair(void) {
+    hipFuncAttributes a;
+    return (int)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(sa_peptide_pair_kernel<13, 4>));
+}
